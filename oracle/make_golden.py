@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference (read-only at /root/reference).
+
+TEST INFRASTRUCTURE ONLY - run in the build container (the GPU box has no /root/reference):
+
+    python oracle/make_golden.py            # writes tests/golden/
+
+What executes reference code here (nothing is copied into the repo; only inputs/outputs are
+stored):
+  * `dota_mixture.DOTA_mix` is imported as a module (it needs only torch).
+  * `Uni_Adapter.py` cannot be imported (needs `clip`, `open_clip`), so the pure functions
+    `softmax_entropy`, `get_logits_wrapper`, `compute_text_alignment_loss` and the
+    `--use-mode-dota` statements of the per-sample loop body (Uni_Adapter.py:388-521) are located
+    with `ast`, compiled from the reference's own syntax tree and executed in a namespace that
+    supplies the loop's free variables.  The encoder is replaced by a feeder that returns
+    pre-generated features (the encoder itself is third-party timm + pointnet2_ops).
+  * `models/point_encoder.py` needs `pointnet2_ops`; only the definitions of
+    `square_distance`, `knn_point`, `Group`, `Encoder` are compiled from its syntax tree, with
+    `fps` supplied explicitly (FPS centres are an input of the fixture).
+  * `models/ulip/pointbert/misc.py:fps` (pure torch) is compiled the same way for the FPS fixture.
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = os.environ.get('UA_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import ref_cpu as O  # noqa: E402  (weights helper only)
+
+
+def _tree(path):
+    with open(path) as f:
+        return ast.parse(f.read(), filename=path)
+
+
+def _exec_defs(path, names, ns):
+    """Compile selected top-level def/class nodes of a reference file into `ns`."""
+    tree = _tree(path)
+    body = [n for n in tree.body
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert {n.name for n in body} == set(names), (names, [n.name for n in body])
+    mod = ast.Module(body=body, type_ignores=[])
+    exec(compile(mod, path, 'exec'), ns)
+    return ns
+
+
+def _loop_body_statements(path):
+    """Statements of the per-sample loop in test_zeroshot_3d_core that form the
+    --use-mode-dota path: text/clip_weights block, get_logits_wrapper call, big if/elif."""
+    tree = _tree(path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'test_zeroshot_3d_core')
+    loops = [n for n in ast.walk(fn) if isinstance(n, ast.For)
+             and isinstance(n.iter, ast.Call) and getattr(n.iter.func, 'id', '') == 'enumerate'
+             and 'test_loader' in ast.unparse(n.iter)]
+    loop = loops[0]
+    keep = []
+    for st in loop.body:
+        src = ast.unparse(st)
+        if isinstance(st, ast.If) and 'text_current' in src and 'clip_weights' in src:
+            keep.append(st)                                    # Uni_Adapter.py:388-401
+        elif isinstance(st, ast.Assign) and 'get_logits_wrapper' in src:
+            keep.append(st)                                    # :406
+        elif isinstance(st, ast.If) and 'mode_dota_model.predict' in src:
+            keep.append(st)                                    # :409-574
+    assert len(keep) == 3, [ast.unparse(s)[:60] for s in keep]
+    return compile(ast.Module(body=keep, type_ignores=[]), path, 'exec')
+
+
+def _fusion_statements(path):
+    """Just the fusion assignments (Uni_Adapter.py:491-521) for the known-answer fixture."""
+    tree = _tree(path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'test_zeroshot_3d_core')
+    want = ('dota_weights_val', 'dota_logits', 'entropy_clip', 'entropy_dota', 'weight_clip',
+            'weight_dota', 'final_logits')
+    assigns = sorted((n for n in ast.walk(fn) if isinstance(n, ast.Assign)
+                      and isinstance(n.targets[0], ast.Name)), key=lambda n: n.lineno)
+    out = []
+    started = False
+    for st in assigns:
+        nm = st.targets[0].id
+        if nm == 'dota_weights_val' and 'mode_dota_model.c.mean' in ast.unparse(st):
+            started = True
+        if started and nm in want:
+            out.append(st)
+            if nm == 'final_logits':
+                break
+    if len(out) < 8:
+        raise RuntimeError('fusion statements not found')
+    return compile(ast.Module(body=out, type_ignores=[]), path, 'exec')
+
+
+class Feeder:
+    """Stands in for the encoder: returns queued features from encode_pc()."""
+    def __init__(self):
+        self.q = []
+    def encode_pc(self, feature):
+        return self.q.pop(0)
+    def float(self):
+        return self
+    def eval(self):
+        return self
+
+
+def make_features(text, n, seed, noise=0.05, aug_noise=0.02):
+    """Synthetic encoder outputs: un-normalised vectors near a random class anchor."""
+    g = torch.Generator().manual_seed(seed)
+    K, D = text.shape
+    labels = torch.randint(0, K, (n,), generator=g)
+    scale = 1.0 + 4.0 * torch.rand(n, 1, generator=g)
+    f = (text[labels] + noise * torch.randn(n, D, generator=g)) * scale
+    fa = (f / scale + aug_noise * torch.randn(n, D, generator=g)) * scale
+    return f.contiguous(), fa.contiguous(), labels
+
+
+def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture):
+    K, D = text.shape
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    f, fa, labels = make_features(text, n_steps, seed)
+    args = types.SimpleNamespace(vlm3d='uni3d', use_dota=False, use_mode_dota=True, res_learning=True,
+                                 print_freq=10 ** 9, device='cpu', use_gmm_dota=False)
+    model = Feeder()
+    text_features = text.clone()
+    text_features_initial = text_features.clone().detach()
+    mdl = dota_mixture.DOTA_mix(cfg, D, K, text_features_initial.T, num_modes=M)
+    mdl.eval()
+    raw = {}
+    orig_predict = mdl.predict
+    def predict_spy(x, source_priors=None):
+        o = orig_predict(x, source_priors)
+        raw['z'] = o.clone()
+        return o
+    mdl.predict = predict_spy
+    text_residuals = torch.zeros_like(text_features_initial, requires_grad=True)
+    opt = torch.optim.Adam([text_residuals], lr=0.001)
+    import logging
+    ns = dict(ua_ns)
+    ns.update(dict(torch=torch, F=F, args=args, model=model, mode_dota_model=mdl, dota_model=None,
+                   dota_cfg=cfg, text_features=text_features, text_features_initial=text_features_initial,
+                   text_residuals=text_residuals, residual_optimizer=opt, residual_lr_start=0.001,
+                   residual_lr_end=0.001, num_batches=n_steps, logging=logging))
+    rec = {k: [] for k in ('clip', 'dota_raw', 'final', 'pred', 'cmean', 'loss', 'w')}
+    snaps = {}
+    init = dict(mu=mdl.mu.clone(), var=mdl.var.clone(), pi=mdl.pi.clone(), c=mdl.c.clone())
+    for i in range(n_steps):
+        model.q = [f[i:i + 1].clone(), fa[i:i + 1].clone()]
+        ns['i'] = i
+        ns['pc'] = torch.zeros(1, 8, 3)
+        ns['rgb'] = torch.ones(1, 8, 3)
+        ns['feature'] = torch.cat((ns['pc'], ns['rgb']), dim=-1)     # Uni_Adapter.py:385
+        with torch.no_grad():
+            exec(loop_code, ns)
+        rec['clip'].append(ns['clip_logits'][0].detach().clone())
+        rec['dota_raw'].append(raw['z'][0].clone())
+        rec['final'].append(ns['final_logits'][0].detach().clone())
+        rec['pred'].append(ns['pred'])
+        rec['cmean'].append(float(mdl.c.mean()))
+        rec['w'].append(float(ns['dota_weights_val']))
+        rec['loss'].append(float(ns['alignment_loss']) if i > 0 else float('nan'))
+        if i in (0, 1, n_steps // 2, n_steps - 1):
+            snaps[i] = dict(c=mdl.c.clone(), pi=mdl.pi.clone(), res=text_residuals.detach().clone())
+    out = dict(
+        text=text.numpy(), M=np.int64(M), feat=f.numpy(), feat_aug=fa.numpy(), labels=labels.numpy(),
+        clip=torch.stack(rec['clip']).numpy(), dota_raw=torch.stack(rec['dota_raw']).numpy(),
+        final=torch.stack(rec['final']).numpy(), pred=np.array(rec['pred'], dtype=np.int64),
+        cmean=np.array(rec['cmean']), w=np.array(rec['w']), loss=np.array(rec['loss']),
+        init_pi=init['pi'].numpy(), init_c=init['c'].numpy(),
+        init_mu_head=init['mu'][:, :, :16].numpy(), init_var_head=init['var'][:, :, :16].numpy(),
+        init_mu_sum=np.float64(init['mu'].double().sum()), init_var_sum=np.float64(init['var'].double().sum()),
+        end_c=mdl.c.numpy(), end_pi=mdl.pi.numpy(), end_class_counts=mdl.class_counts.numpy(),
+        end_mu_head=mdl.mu[:, :, :16].numpy(), end_var_head=mdl.var[:, :, :16].numpy(),
+        end_mu_sum=np.float64(mdl.mu.double().sum()), end_var_sum=np.float64(mdl.var.double().sum()),
+        end_res=text_residuals.detach().numpy(),
+        end_adam_m=opt.state[text_residuals]['exp_avg'].numpy(),
+        end_adam_v=opt.state[text_residuals]['exp_avg_sq'].numpy(),
+        snap_steps=np.array(sorted(snaps)),
+    )
+    for s, d in snaps.items():
+        out[f'snap{s}_c'] = d['c'].numpy()
+        out[f'snap{s}_pi'] = d['pi'].numpy()
+        out[f'snap{s}_res_head'] = d['res'][:, :32].numpy()
+    return out, mdl, text_residuals.detach().clone()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)            # fixes CPU reduction order for reproducible fixtures
+    sys.path.insert(0, REF)
+    import dota_mixture                                                     # reference module
+    ua_path = os.path.join(REF, 'Uni_Adapter.py')
+    ua_ns = {'torch': torch, 'F': F, 'np': np}
+    _exec_defs(ua_path, ['softmax_entropy', 'get_logits_wrapper', 'compute_text_alignment_loss'], ua_ns)
+    loop_code = _loop_body_statements(ua_path)
+    fusion_code = _fusion_statements(ua_path)
+
+    tf = os.path.join(REF, 'precomputed_text_features', 'Uni3D')
+    banks = {
+        'modelnet40': torch.load(os.path.join(tf, 'text_features_large.pt'), map_location='cpu', weights_only=True),
+        'scanobjectnn': torch.load(os.path.join(tf, 'text_features_large_scanobjectnn.pt'), map_location='cpu', weights_only=True),
+        'shapenet55': torch.load(os.path.join(tf, 'text_features_large_shapenetcorev2.pt'), map_location='cpu', weights_only=True),
+    }
+    banks = {k: v.float().contiguous() for k, v in banks.items()}
+
+    # ---- G1/G2: init + full loop-body stream (reference DOTA_mix + loop statements) ----
+    for name, M, n, seed in (('modelnet40', 8, 48, 11), ('scanobjectnn', 8, 24, 12), ('shapenet55', 4, 16, 13)):
+        out, mdl, res = run_stream(banks[name], M, n, seed, ua_ns, loop_code, dota_mixture)
+        np.savez_compressed(os.path.join(OUT, f'g2_stream_{name}.npz'), **out)
+        print('g2', name, 'preds', out['pred'][:8], 'final[0,:3]', out['final'][0, :3])
+        if name == 'scanobjectnn':
+            # ---- G3: alignment loss / matrix / gradient on the end state (K=15) ----
+            text0 = banks[name]
+            r = res.clone().requires_grad_(True)
+            e = text0 + r
+            e = e / e.norm(dim=1, keepdim=True)
+            loss, Lm = ua_ns['compute_text_alignment_loss'](e, mdl)
+            (g,) = torch.autograd.grad(loss, r)
+            row3 = mdl.predict(e[3:4].detach())
+            np.savez_compressed(os.path.join(OUT, 'g3_alignment_scanobjectnn.npz'),
+                                text=text0.numpy(), res=res.numpy(), mu=mdl.mu.numpy(), var=mdl.var.numpy(),
+                                pi=mdl.pi.numpy(), c=mdl.c.numpy(), eps=np.float64(mdl.epsilon),
+                                loss=np.float64(loss.item()), L=Lm.detach().numpy(), grad_res=g.numpy(),
+                                predict_row3=row3.numpy())
+            print('g3 loss', loss.item())
+
+    # ---- cache-only stream without residual learning, B>1 fit (DOTA_mix API surface) ----
+    text = banks['scanobjectnn']
+    K, D = text.shape
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4}
+    mdl = dota_mixture.DOTA_mix(cfg, D, K, text.T, num_modes=4)
+    g = torch.Generator().manual_seed(5)
+    xs, gs, zs = [], [], []
+    for it in range(6):
+        B = (1, 3, 2, 4, 1, 5)[it]
+        lab = torch.randint(0, K, (B,), generator=g)
+        x = F.normalize(text[lab] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+        gam = torch.softmax(100 * x @ text.T, 1)
+        zs.append(mdl.predict(x.half()).clone())
+        mdl.fit(x, gam)
+        xs.append(x); gs.append(gam)
+    np.savez_compressed(os.path.join(OUT, 'g2b_batched_fit.npz'), text=text.numpy(), M=np.int64(4),
+                        **{f'x{i}': xs[i].numpy() for i in range(6)}, **{f'g{i}': gs[i].numpy() for i in range(6)},
+                        **{f'z{i}': zs[i].numpy() for i in range(6)},
+                        end_mu=mdl.mu.numpy(), end_var=mdl.var.numpy(), end_c=mdl.c.numpy(), end_pi=mdl.pi.numpy(),
+                        end_class_counts=mdl.class_counts.numpy(), end_t=np.int64(mdl.t))
+
+    # ---- sigma auto-correction branch (dota_mixture.py:46-54) ----
+    m2 = dota_mixture.DOTA_mix({'epsilon': 1e-3, 'sigma': 1.0}, D, K, text.T, num_modes=3)
+    np.savez_compressed(os.path.join(OUT, 'g1_init_sigma_autocorrect.npz'), text=text.numpy(),
+                        mu_head=m2.mu[:, :, :8].numpy(), var_head=m2.var[:, :, :8].numpy(),
+                        pi=m2.pi.numpy(), c=m2.c.numpy())
+
+    # ---- G4: fusion known answers (reference statements :491-521) ----
+    g = torch.Generator().manual_seed(7)
+    cases = []
+    for t in range(8):
+        Kc = (40, 15, 55, 40, 7, 40, 40, 3)[t]
+        clip_z = 100 * (0.1 + 0.2 * torch.rand(1, Kc, generator=g))
+        dota_z = 1500 + 1500 * torch.rand(1, Kc, generator=g)
+        c = (1.0 / 8) + (10 ** (t - 3)) * torch.rand(Kc, 8, generator=g)
+        ns = dict(ua_ns)
+        ns.update(dict(torch=torch, dota_cfg={'rho': 0.02, 'eta': 0.1}, pc_features=torch.zeros(1, 4),
+                       mode_dota_model=types.SimpleNamespace(c=c), clip_logits=clip_z.clone(),
+                       dota_logits=dota_z.clone()))
+        exec(fusion_code, ns)
+        cases.append((clip_z, dota_z, c, ns['final_logits'].clone(), float(ns['dota_weights_val'])))
+    np.savez_compressed(os.path.join(OUT, 'g4_fusion.npz'), n=np.int64(len(cases)),
+                        **{f'clip{i}': c[0].numpy() for i, c in enumerate(cases)},
+                        **{f'dota{i}': c[1].numpy() for i, c in enumerate(cases)},
+                        **{f'c{i}': c[2].numpy() for i, c in enumerate(cases)},
+                        **{f'final{i}': c[3].numpy() for i, c in enumerate(cases)},
+                        w=np.array([c[4] for c in cases]))
+
+    # ---- G5/G6: grouping + mini-PointNet from models/point_encoder.py ----
+    pe_path = os.path.join(REF, 'models', 'point_encoder.py')
+    box = {}
+    def given_fps(xyz, number):                        # FPS centres are a fixture INPUT
+        return box['centers']
+    pe_ns = {'torch': torch, 'nn': nn, 'fps': given_fps, 'logging': __import__('logging')}
+    _exec_defs(pe_path, ['square_distance', 'knn_point', 'Group', 'Encoder'], pe_ns)
+    g = torch.Generator().manual_seed(21)
+    xyz = torch.randn(2, 1024, 3, generator=g)
+    xyz = xyz / xyz.norm(dim=-1).max()
+    xyz[1, 100:110] = xyz[1, 90:100]                   # duplicate points -> exact distance ties
+    rgb = torch.rand(2, 1024, 3, generator=g)
+    cidx = O.fps(xyz, 128, start=0, skip_origin_eps=-1.0)
+    centers = xyz[torch.arange(2)[:, None], cidx]
+    box['centers'] = centers
+    sq = pe_ns['square_distance'](centers, xyz)
+    grp = pe_ns['Group'](num_group=128, group_size=32)
+    nb, cen, feat = grp(xyz, rgb)
+    idx = pe_ns['knn_point'](32, xyz, centers)
+    np.savez_compressed(os.path.join(OUT, 'g5_group.npz'), xyz=xyz.numpy(), rgb=rgb.numpy(),
+                        center_idx=cidx.numpy(), sqdist_rows=sq[:, :4].numpy(),
+                        idx_sorted=idx.sort(-1)[0].numpy(),
+                        feat_sorted_sum=feat.double().sum((2,)).numpy(), feat_g0=feat[:, :2].numpy(),
+                        idx_g0=idx[:, :2].numpy())
+    sd = O.make_uni3d_state_dict(3, trans_dim=64, embed_dim=32, enc_dim=512, depth=0)
+    enc = pe_ns['Encoder'](encoder_channel=512)
+    enc.load_state_dict({k[len('point_encoder.encoder.'):]: v for k, v in sd.items()
+                         if k.startswith('point_encoder.encoder.')}, strict=False)
+    enc.eval()
+    with torch.no_grad():
+        tok = enc(feat[:, :16])
+    np.savez_compressed(os.path.join(OUT, 'g6_patch_encoder.npz'), feat=feat[:, :16].numpy(),
+                        weights_seed=np.int64(3), tokens=tok.numpy(),
+                        **{'w_' + k[len('point_encoder.encoder.'):]: v.numpy() for k, v in sd.items()
+                           if k.startswith('point_encoder.encoder.first_conv')})
+    print('g6 tokens', tok.shape, tok[0, 0, :3])
+
+    # ---- G7: pure-torch FPS (models/ulip/pointbert/misc.py:40-60) with recorded start ----
+    misc_ns = {'torch': torch, 'np': np}
+    _exec_defs(os.path.join(REF, 'models', 'ulip', 'pointbert', 'misc.py'), ['fps', 'index_points'], misc_ns)
+    torch.manual_seed(1234)
+    start = int(torch.randint(0, 1024, (1,), dtype=torch.long))   # same draw the reference makes
+    torch.manual_seed(1234)
+    pts = misc_ns['fps'](xyz[:1], 64)
+    np.savez_compressed(os.path.join(OUT, 'g7_fps.npz'), xyz=xyz[:1].numpy(), start=np.int64(start),
+                        centers=pts.numpy())
+    print('g7 start', start)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print('golden bytes', tot)
+
+
+if __name__ == '__main__':
+    main()

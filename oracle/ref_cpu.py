@@ -1,0 +1,540 @@
+"""CPU oracle for the Uni-Adapter per-sample test-time hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a from-scratch PyTorch-CPU restatement of the
+reference algorithm (citations are `file:line` under /root/reference).  It exists to CHECK
+the HIP path; nothing in the product package (`uni-adapter_amd/`) may import it.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * cache step  (gmm_init / gmm_predict / gmm_fit, A8-A11)   - pinned, bit-exact vs the imported
+    reference `dota_mixture.DOTA_mix` (tests/golden/g1_*, g2_*; oracle/make_golden.py)
+  * clip logits / entropy / fusion / alignment loss (A7, A12, A13) - pinned vs functions extracted
+    from the reference `Uni_Adapter.py` (g2_*, g3_*, g4_*)
+  * square_distance / knn_point / Group / Encoder (A2-A4)     - pinned vs `models/point_encoder.py`
+    definitions executed with FPS supplied explicitly (g5_*, g6_*)
+  * farthest point sampling (A1)  - pinned only for the pure-torch flavour
+    (`models/ulip/pointbert/misc.py:40-60`, g7_*); the pointnet2_ops CUDA flavour
+    (start index 0, skip |p|^2<=1e-3) is third-party and absent: PARITY UNPINNED
+  * timm EVA02 blocks (A6) - third-party, absent: PARITY UNPINNED; restated from the structure
+    recorded in SURVEY.md row A6 / `extract_attention.py:121-177`
+
+All functions take/return torch CPU tensors; `dtype` selects fp32 (reference arithmetic) or
+fp64 (used by tests as the "true value" to bound fp32 noise).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# ======================================================================================
+# A8-A11  MODE-DOTA cache: per-class M-mode diagonal Gaussian mixture, streaming EM
+# ======================================================================================
+@dataclass
+class GmmState:
+    """State of `DOTA_mix` (dota_mixture.py:62-111).  mu/var (K,M,D); pi/c (K,M)."""
+    mu: torch.Tensor
+    var: torch.Tensor
+    pi: torch.Tensor
+    c: torch.Tensor
+    class_counts: torch.Tensor
+    epsilon: float
+    t: int = 0
+
+    @property
+    def K(self): return self.mu.shape[0]
+    @property
+    def M(self): return self.mu.shape[1]
+    @property
+    def D(self): return self.mu.shape[2]
+
+    def clone(self) -> "GmmState":
+        return GmmState(self.mu.clone(), self.var.clone(), self.pi.clone(), self.c.clone(),
+                        self.class_counts.clone(), self.epsilon, self.t)
+
+
+def gmm_init(text_kd: torch.Tensor, num_modes: int, sigma: float, epsilon: float,
+             dtype=torch.float32) -> GmmState:
+    """dota_mixture.py:20-111.  `text_kd` is (K,D) = clip_weights.T of the reference ctor."""
+    K, D = text_kd.shape
+    M = num_modes
+    sigma_init = (1.0 / D) if sigma >= 0.1 else sigma            # :46-54
+    delta = sigma_init * 0.1                                      # :70
+    center = text_kd.to(torch.float32)
+    mu = center[:, None, :].repeat(1, M, 1)
+    # each mode m is shifted along axis (m mod D) by delta*(m+1); the reference builds a zero
+    # offset row and ADDS it (":76-79"), so untouched coordinates see "+0.0" (identity in fp32)
+    for m in range(M):
+        off = torch.tensor(delta * (m + 1), dtype=torch.float32)
+        mu[:, m, m % D] = center[:, m % D] + off
+    var = torch.ones(K, M, D, dtype=torch.float32) * sigma_init   # :86-87
+    for m in range(M):
+        var[:, m, :] *= (1.0 + 0.05 * m)                          # :91-93
+    var = var.clamp(min=1e-8)                                     # :96
+    pi = torch.ones(K, M, dtype=torch.float32) / M                # :102
+    c = torch.full((K, M), 1.0 / M, dtype=torch.float32)          # :106
+    cc = torch.zeros(K, dtype=torch.float32)
+    st = GmmState(mu, var, pi, c, cc, float(epsilon), 0)
+    if dtype != torch.float32:
+        st = GmmState(mu.to(dtype), var.to(dtype), pi.to(dtype), c.to(dtype), cc.to(dtype),
+                      float(epsilon), 0)
+    return st
+
+
+def gmm_get_var(st: GmmState) -> torch.Tensor:
+    """dota_mixture.py:117-119."""
+    return (st.var + st.epsilon).clamp(min=1e-8)
+
+
+def gmm_log_likelihood(x: torch.Tensor, mu: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
+    """dota_mixture.py:121-156: -(1/2)[sum_d ln v + sum_d (x-mu)^2/v], constant dropped.
+    x (B,D); mu,var (K,M,D) -> (B,K,M).  Differentiable w.r.t. x (used by A13)."""
+    diff = x[:, None, None, :] - mu[None]
+    maha = (diff * diff / var[None]).sum(-1)
+    log_det = var.log().sum(-1)[None]
+    return -0.5 * (log_det + maha)
+
+
+def gmm_joint(st: GmmState, x: torch.Tensor) -> torch.Tensor:
+    """log(pi+1e-10) + log-lik, (B,K,M) (dota_mixture.py:177-180 / :254-255)."""
+    ll = gmm_log_likelihood(x, st.mu, gmm_get_var(st))
+    return torch.log(st.pi + 1e-10)[None] + ll
+
+
+def gmm_predict(st: GmmState, x: torch.Tensor) -> torch.Tensor:
+    """dota_mixture.py:236-267 (source_priors branch never taken).  x any float dtype."""
+    x = x.to(st.mu.dtype)
+    return torch.logsumexp(gmm_joint(st, x), dim=2)
+
+
+def gmm_fit(st: GmmState, x: torch.Tensor, gamma_class: torch.Tensor) -> None:
+    """dota_mixture.py:162-234, in place.  x (B,D), gamma_class (B,K)."""
+    dt = st.mu.dtype
+    x = x.to(dt)
+    g = gamma_class.to(dt)
+    lj = gmm_joint(st, x)                                         # E-step :176-180
+    r = torch.exp(lj - torch.logsumexp(lj, dim=2, keepdim=True))  # :183-184
+    gam = g[:, :, None] * r                                       # (B,K,M)  :187
+    s_g = gam.sum(0)                                              # :190
+    c0, mu0, var0 = st.c, st.mu, st.var
+    c1 = c0 + s_g                                                 # :196
+    gp = gam.permute(1, 2, 0)                                     # (K,M,B)
+    wx = gp @ x                                                   # :202
+    mu1 = (c0[..., None] * mu0 + wx) / (c1[..., None] + 1e-10)    # :205-206
+    wxx = gp @ (x ** 2)                                           # :213-214
+    sq = wxx + (-2.0 * mu0 * wx) + s_g[..., None] * (mu0 ** 2)    # :215-217 (old mu)
+    var1 = (c0[..., None] * var0 + sq) / (c1[..., None] + 1e-10)  # :219-220
+    st.var = var1.clamp(min=1e-8)                                 # :223
+    st.mu = mu1
+    st.c = c1
+    st.pi = c1 / (c1.sum(1, keepdim=True) + 1e-10)                # :229-230
+    st.class_counts = st.class_counts + g.sum(0)                  # :233
+    st.t += x.shape[0]
+
+
+# ======================================================================================
+# A7 / A12  zero-shot logits, entropy, fusion
+# ======================================================================================
+def softmax_entropy(z: torch.Tensor) -> torch.Tensor:
+    """Uni_Adapter.py:21-26: H = -sum p ln(p+1e-10), p = softmax(z, dim=1)."""
+    p = torch.softmax(z, dim=1)
+    return -(p * torch.log(p + 1e-10)).sum(1)
+
+
+def clip_logits(feat: torch.Tensor, text_kd: torch.Tensor):
+    """Uni_Adapter.py:53-75 for vlm3d=='uni3d', given the encoder output `feat` (B,D) and the
+    CURRENT text matrix (K,D) (the reference passes its transpose, (D,K)).
+    Returns f_hat, logits, entropy, prob_map, pred."""
+    f = feat / feat.norm(dim=-1, keepdim=True)
+    z = 100.0 * f @ text_kd.t()
+    ent = softmax_entropy(z)
+    prob = z.softmax(1)
+    pred = z.argmax(1)
+    return f, z, ent, prob, pred
+
+
+def current_text(text0: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+    """Uni_Adapter.py:388-393: normalize(text_initial + residual) per row, (K,D)."""
+    if residual is None:
+        return text0
+    return F.normalize(text0 + residual, dim=1)
+
+
+def fuse_logits(clip_z: torch.Tensor, dota_z: torch.Tensor, c: torch.Tensor,
+                rho: float, eta: float, batch: int = 1):
+    """Uni_Adapter.py:491-521, including the weight-reuse quirk at :512-513."""
+    w = torch.clamp(rho * c.mean() / batch, max=eta)
+    d = w * dota_z
+    hc = softmax_entropy(clip_z)
+    hd = softmax_entropy(d)
+    wc = 1 / (hc + 1e-3)
+    wd = 1 / (hd + 1e-3)
+    wc = wc / (wc + wd)
+    wd = wd / (wc + wd)          # uses the already-normalised wc (reference quirk)
+    return wc * clip_z + wd * d
+
+
+def accuracy_topk(z: torch.Tensor, target: torch.Tensor, topk=(1, 3, 5)) -> List[float]:
+    """utils/utils.py:154-167, percentages."""
+    maxk = max(topk)
+    pred = z.topk(maxk, 1, True, True)[1].t()
+    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+    return [float(correct[:k].reshape(-1).float().sum() * (100.0 / target.shape[0])) for k in topk]
+
+
+# ======================================================================================
+# A13  residual learning of the text anchors
+# ======================================================================================
+def alignment_matrix(st: GmmState, e: torch.Tensor) -> torch.Tensor:
+    """Uni_Adapter.py:219-244: L[i,k] = logsumexp_m(ln(pi+1e-10) + ll(e_i; k,m)), (K,K)."""
+    return torch.logsumexp(gmm_joint(st, e), dim=2)
+
+
+def alignment_loss_from_matrix(L: torch.Tensor) -> torch.Tensor:
+    """Uni_Adapter.py:248-253."""
+    P = torch.exp(torch.exp(L / L.max()))
+    dg = torch.diag(P)
+    return -(dg / P.sum(1)).mean() - (dg / P.sum(0)).mean()
+
+
+def alignment_loss_grad(L: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Closed-form dLoss/dL of `alignment_loss_from_matrix` (what the HIP kernel implements);
+    checked against autograd in tests."""
+    K = L.shape[0]
+    mx = L.max()
+    Ln = L / mx
+    E = torch.exp(Ln)
+    P = torch.exp(E)
+    s1, s2 = P.sum(1), P.sum(0)
+    dg = torch.diag(P)
+    loss = -(dg / s1).mean() - (dg / s2).mean()
+    eye = torch.eye(K, dtype=L.dtype)
+    dP = -(eye / s1[:, None] - (dg / s1 ** 2)[:, None]) / K - (eye / s2[None, :] - (dg / s2 ** 2)[None, :]) / K
+    dLn = dP * P * E
+    G = dLn / mx
+    flat = int(torch.argmax(L))
+    G.view(-1)[flat] += -(dLn * L).sum() / (mx * mx)
+    return loss, G
+
+
+@dataclass
+class AdamState:
+    """torch.optim.Adam([p], lr=1e-3) defaults (Uni_Adapter.py:350-352)."""
+    m: torch.Tensor
+    v: torch.Tensor
+    step: int = 0
+    lr: float = 1e-3
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, a: AdamState) -> None:
+    """Single-tensor Adam exactly as torch.optim.adam._single_tensor_adam (no amsgrad /
+    weight decay): lerp for m, mul+addcmul for v, sqrt/bias-corr/+eps, addcdiv."""
+    a.step += 1
+    a.m.lerp_(g, 1 - a.b1)
+    a.v.mul_(a.b2).addcmul_(g, g, value=1 - a.b2)
+    bc1 = 1 - a.b1 ** a.step
+    bc2 = 1 - a.b2 ** a.step
+    step_size = a.lr / bc1
+    denom = (a.v.sqrt() / math.sqrt(bc2)).add_(a.eps)
+    p.addcdiv_(a.m, denom, value=-step_size)
+
+
+def residual_learning(st: GmmState, text0: torch.Tensor, res: torch.Tensor, adam: AdamState,
+                      n_steps: int = 10) -> Tuple[float, torch.Tensor]:
+    """Uni_Adapter.py:444-476: loss eval, then n_steps x (backward, Adam, loss eval).
+    `res` and `adam` are updated in place.  Returns (last loss, last likelihood matrix)."""
+    def evaluate():
+        r = res.detach().clone().requires_grad_(True)
+        t = text0 + r
+        e = t / t.norm(dim=1, keepdim=True)
+        L = alignment_matrix(st, e)
+        return alignment_loss_from_matrix(L), L, r
+    loss, L, r = evaluate()
+    for _ in range(n_steps):
+        (g,) = torch.autograd.grad(loss, r)
+        adam_step(res, g, adam)
+        loss, L, r = evaluate()
+    return float(loss.detach()), L.detach()
+
+
+# ======================================================================================
+# A1-A3  grouping
+# ======================================================================================
+def fps(xyz: torch.Tensor, n_centers: int, start: int = 0,
+        skip_origin_eps: float = -1.0) -> torch.Tensor:
+    """Iterative farthest point sampling, returns indices (B,G) int64.
+    Pure-torch flavour: models/ulip/pointbert/misc.py:40-60 with the start index made an
+    explicit input (the reference draws it with torch.randint).
+    `skip_origin_eps >= 0` reproduces the pointnet2_ops CUDA convention used by
+    models/point_encoder.py:7-14 (points with |p|^2 <= eps never update / never win);
+    that flavour is third-party and unpinned."""
+    B, N, _ = xyz.shape
+    idx = torch.zeros(B, n_centers, dtype=torch.long)
+    mind = torch.full((B, N), 1e10, dtype=xyz.dtype)
+    far = torch.full((B,), int(start), dtype=torch.long)
+    ar = torch.arange(B)
+    if skip_origin_eps >= 0:
+        live = (xyz ** 2).sum(-1) > skip_origin_eps
+    for i in range(n_centers):
+        idx[:, i] = far
+        c = xyz[ar, far][:, None, :]
+        d = ((xyz - c) ** 2).sum(-1)
+        mind = torch.minimum(mind, d)
+        cand = mind if skip_origin_eps < 0 else torch.where(live, mind, torch.full_like(mind, -1.0))
+        far = cand.argmax(-1)
+    return idx
+
+
+def square_distance(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """models/point_encoder.py:30-49: expanded form -2 s.d + |s|^2 + |d|^2 (NOT (s-d)^2)."""
+    d = -2 * (src @ dst.transpose(1, 2))
+    d = d + (src ** 2).sum(-1)[:, :, None]
+    d = d + (dst ** 2).sum(-1)[:, None, :]
+    return d
+
+
+def knn_point(k: int, xyz: torch.Tensor, centers: torch.Tensor) -> torch.Tensor:
+    """models/point_encoder.py:17-28: indices of the k smallest expanded-form distances;
+    order inside a group is unspecified in the reference (sorted=False) - returned sorted by
+    index so sets can be compared."""
+    d = square_distance(centers, xyz)
+    idx = d.topk(k, dim=-1, largest=False, sorted=False)[1]
+    return idx.sort(-1)[0]
+
+
+def group_points(xyz: torch.Tensor, rgb: torch.Tensor, center_idx: torch.Tensor, group_size: int):
+    """models/point_encoder.py:99-127 with FPS indices given.  Returns (center (B,G,3),
+    features (B,G,S,6) = [xyz - center, rgb], idx (B,G,S))."""
+    B = xyz.shape[0]
+    ar = torch.arange(B)[:, None]
+    center = xyz[ar, center_idx]
+    idx = knn_point(group_size, xyz, center)
+    nb = xyz[ar[:, :, None], idx] - center[:, :, None, :]
+    col = rgb[ar[:, :, None], idx]
+    return center, torch.cat([nb, col], -1), idx
+
+
+# ======================================================================================
+# A4-A6  encoder
+# ======================================================================================
+def _bn_eval(x, w, b, rm, rv, eps=1e-5):
+    return (x - rm) / torch.sqrt(rv + eps) * w + b
+
+
+def patch_encoder(feat: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    """models/point_encoder.py:129-159 (BatchNorm in eval).  feat (B,G,S,Cin) -> (B,G,Cout)."""
+    B, G, S, Cin = feat.shape
+    p = lambda n: sd[prefix + n]
+    x = feat.reshape(B * G * S, Cin)
+    x = x @ p('first_conv.0.weight')[:, :, 0].t() + p('first_conv.0.bias')
+    x = torch.relu(_bn_eval(x, p('first_conv.1.weight'), p('first_conv.1.bias'),
+                            p('first_conv.1.running_mean'), p('first_conv.1.running_var')))
+    x = x @ p('first_conv.3.weight')[:, :, 0].t() + p('first_conv.3.bias')        # (BGS,256)
+    x = x.reshape(B * G, S, -1)
+    g = x.max(1, keepdim=True)[0].expand(-1, S, -1)
+    x = torch.cat([g, x], -1).reshape(B * G * S, -1)                               # (.,512)
+    x = x @ p('second_conv.0.weight')[:, :, 0].t() + p('second_conv.0.bias')
+    x = torch.relu(_bn_eval(x, p('second_conv.1.weight'), p('second_conv.1.bias'),
+                            p('second_conv.1.running_mean'), p('second_conv.1.running_var')))
+    x = x @ p('second_conv.3.weight')[:, :, 0].t() + p('second_conv.3.bias')
+    return x.reshape(B * G, S, -1).max(1)[0].reshape(B, G, -1)
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def eva_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], pre: str, n_heads: int,
+              ln_eps: float = 1e-6) -> torch.Tensor:
+    """timm EvaBlock as instantiated by eva02_large_patch14_448 and called WITHOUT rope
+    (models/uni3d.py:38, models/point_encoder.py:217-218; structure per SURVEY row A6 and
+    extract_attention.py:121-177).  Key-driven: separate q/k/v projections or fused qkv
+    (+q_bias/v_bias), optional attn.norm, SwiGLU (fc1_g/fc1_x + mlp.norm) or plain GELU MLP,
+    optional gamma_1/gamma_2.  THIRD-PARTY STRUCTURE - PARITY UNPINNED."""
+    has = lambda k: (pre + k) in sd
+    p = lambda k: sd[pre + k]
+    B, T, C = x.shape
+    hd = C // n_heads
+    h = _ln(x, p('norm1.weight'), p('norm1.bias'), ln_eps)
+    if has('attn.q_proj.weight'):
+        q = h @ p('attn.q_proj.weight').t()
+        k = h @ p('attn.k_proj.weight').t()
+        v = h @ p('attn.v_proj.weight').t()
+        if has('attn.q_proj.bias'): q = q + p('attn.q_proj.bias')
+        if has('attn.k_proj.bias'): k = k + p('attn.k_proj.bias')
+        if has('attn.v_proj.bias'): v = v + p('attn.v_proj.bias')
+        if has('attn.q_bias'): q = q + p('attn.q_bias')
+        if has('attn.v_bias'): v = v + p('attn.v_bias')
+    else:
+        qkv = h @ p('attn.qkv.weight').t()
+        if has('attn.qkv.bias'):
+            qkv = qkv + p('attn.qkv.bias')
+        q, k, v = qkv.split(C, dim=-1)
+        if has('attn.q_bias'): q = q + p('attn.q_bias')
+        if has('attn.v_bias'): v = v + p('attn.v_bias')
+    q = q.reshape(B, T, n_heads, hd).transpose(1, 2)
+    k = k.reshape(B, T, n_heads, hd).transpose(1, 2)
+    v = v.reshape(B, T, n_heads, hd).transpose(1, 2)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, T, C)
+    if has('attn.norm.weight'):
+        a = _ln(a, p('attn.norm.weight'), p('attn.norm.bias'), ln_eps)
+    a = a @ p('attn.proj.weight').t() + p('attn.proj.bias')
+    if has('gamma_1'): a = a * p('gamma_1')
+    x = x + a
+    h = _ln(x, p('norm2.weight'), p('norm2.bias'), ln_eps)
+    if has('mlp.fc1_g.weight'):
+        g = h @ p('mlp.fc1_g.weight').t() + p('mlp.fc1_g.bias')
+        u = h @ p('mlp.fc1_x.weight').t() + p('mlp.fc1_x.bias')
+        h = F.silu(g) * u
+        if has('mlp.norm.weight'):
+            h = _ln(h, p('mlp.norm.weight'), p('mlp.norm.bias'), ln_eps)
+    else:
+        h = F.gelu(h @ p('mlp.fc1.weight').t() + p('mlp.fc1.bias'))
+    h = h @ p('mlp.fc2.weight').t() + p('mlp.fc2.bias')
+    if has('gamma_2'): h = h * p('gamma_2')
+    return x + h
+
+
+def uni3d_encode_pc(pc6: torch.Tensor, sd: Dict[str, torch.Tensor], num_group: int,
+                    group_size: int, n_heads: int, fps_start: int = 0,
+                    fps_skip_eps: float = 1e-3, ln_eps: float = 1e-6,
+                    prefix: str = 'point_encoder.', return_tokens: bool = False):
+    """models/uni3d.py:15-19 + models/point_encoder.py:192-223.  pc6 (B,N,6) -> (B,D)."""
+    P = prefix
+    xyz, rgb = pc6[:, :, :3].contiguous(), pc6[:, :, 3:].contiguous()
+    cidx = fps(xyz, num_group, start=fps_start, skip_origin_eps=fps_skip_eps)
+    center, feat, _ = group_points(xyz, rgb, cidx, group_size)
+    tok = patch_encoder(feat, sd, P + 'encoder.')
+    tok = tok @ sd[P + 'encoder2trans.weight'].t() + sd[P + 'encoder2trans.bias']
+    pos = F.gelu(center @ sd[P + 'pos_embed.0.weight'].t() + sd[P + 'pos_embed.0.bias'])
+    pos = pos @ sd[P + 'pos_embed.2.weight'].t() + sd[P + 'pos_embed.2.bias']
+    B = pc6.shape[0]
+    x = torch.cat([sd[P + 'cls_token'].expand(B, -1, -1), tok], 1)
+    x = x + torch.cat([sd[P + 'cls_pos'].expand(B, -1, -1), pos], 1)
+    n_blocks = 1 + max(int(k.split('.')[3]) for k in sd if k.startswith(P + 'visual.blocks.'))
+    for i in range(n_blocks):
+        x = eva_block(x, sd, f'{P}visual.blocks.{i}.', n_heads, ln_eps)
+    tokens = x
+    x = x[:, 0, :]
+    if (P + 'visual.norm.weight') in sd:
+        x = _ln(x, sd[P + 'visual.norm.weight'], sd[P + 'visual.norm.bias'], ln_eps)
+    if (P + 'visual.fc_norm.weight') in sd:
+        x = _ln(x, sd[P + 'visual.fc_norm.weight'], sd[P + 'visual.fc_norm.bias'], ln_eps)
+    x = x @ sd[P + 'trans2embed.weight'].t() + sd[P + 'trans2embed.bias']
+    return (x, tokens) if return_tokens else x
+
+
+def make_uni3d_state_dict(seed: int, trans_dim: int, embed_dim: int, enc_dim: int, depth: int,
+                          hidden: Optional[int] = None, in_ch: int = 6,
+                          use_fc_norm: bool = True, std: float = 0.02,
+                          dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights in the reference's state-dict key layout (after stripping
+    `module.`, utils/load_models.py:56-59).  Shapes per models/point_encoder.py:129-186 and
+    eva02_large (SURVEY section 8 cfg table).  BN running stats are randomised mildly so that the
+    BN arithmetic is actually exercised."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: (torch.randn(*s, generator=g) * std).to(dtype)
+    C, H = trans_dim, hidden if hidden is not None else int(trans_dim * 8 / 3)
+    P = 'point_encoder.'
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, co, ci):
+        sd[P + name + '.weight'] = (torch.randn(co, ci, 1, generator=g) / math.sqrt(ci)).to(dtype)
+        sd[P + name + '.bias'] = rn(co)
+
+    def bn(name, c):
+        sd[P + name + '.weight'] = (1 + 0.1 * torch.randn(c, generator=g)).to(dtype)
+        sd[P + name + '.bias'] = (0.1 * torch.randn(c, generator=g)).to(dtype)
+        sd[P + name + '.running_mean'] = (0.1 * torch.randn(c, generator=g)).to(dtype)
+        sd[P + name + '.running_var'] = (1 + 0.2 * torch.rand(c, generator=g)).to(dtype)
+
+    def lin(name, co, ci, s=None):
+        sd[P + name + '.weight'] = (torch.randn(co, ci, generator=g) * (s or 1 / math.sqrt(ci))).to(dtype)
+        sd[P + name + '.bias'] = rn(co)
+
+    def ln(name, c):
+        sd[P + name + '.weight'] = (1 + 0.05 * torch.randn(c, generator=g)).to(dtype)
+        sd[P + name + '.bias'] = (0.05 * torch.randn(c, generator=g)).to(dtype)
+
+    conv('encoder.first_conv.0', 128, in_ch); bn('encoder.first_conv.1', 128)
+    conv('encoder.first_conv.3', 256, 128)
+    conv('encoder.second_conv.0', 512, 512); bn('encoder.second_conv.1', 512)
+    conv('encoder.second_conv.3', enc_dim, 512)
+    lin('encoder2trans', C, enc_dim)
+    lin('trans2embed', embed_dim, C)
+    sd[P + 'cls_token'] = rn(1, 1, C)
+    sd[P + 'cls_pos'] = torch.randn(1, 1, C, generator=g).to(dtype) * 0.1
+    lin('pos_embed.0', 128, 3); lin('pos_embed.2', C, 128)
+    for i in range(depth):
+        b = f'visual.blocks.{i}.'
+        ln(b + 'norm1', C); ln(b + 'norm2', C)
+        lin(b + 'attn.q_proj', C, C); lin(b + 'attn.v_proj', C, C); lin(b + 'attn.proj', C, C)
+        sd[P + b + 'attn.k_proj.weight'] = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+        lin(b + 'mlp.fc1_g', H, C); lin(b + 'mlp.fc1_x', H, C); ln(b + 'mlp.norm', H)
+        lin(b + 'mlp.fc2', C, H)
+    ln('visual.fc_norm' if use_fc_norm else 'visual.norm', C)
+    sd['logit_scale'] = torch.tensor(math.log(1 / 0.07), dtype=dtype)
+    return sd
+
+
+# ======================================================================================
+# A14  per-sample loop (cache part; encoder outputs are inputs)
+# ======================================================================================
+@dataclass
+class TtaConfig:
+    """utils/params.py:103-111 defaults + the loop constants (Uni_Adapter.py:420,467)."""
+    epsilon: float = 1e-4
+    sigma: float = 1e-4
+    eta: float = 0.1
+    rho: float = 0.02
+    num_modes: int = 8
+    res_learning: bool = True
+    res_steps: int = 10
+
+
+@dataclass
+class TtaTrace:
+    clip_logits: List[torch.Tensor] = field(default_factory=list)
+    dota_logits: List[torch.Tensor] = field(default_factory=list)
+    final_logits: List[torch.Tensor] = field(default_factory=list)
+    preds: List[int] = field(default_factory=list)
+
+
+class TtaStream:
+    """The loop body of Uni_Adapter.py:368-579 for --use-mode-dota, fed with encoder outputs:
+    `feat` = encode_pc(cloud), `feat_aug` = encode_pc(cloud + 0.05*noise)  (both (1,D))."""
+
+    def __init__(self, text_kd: torch.Tensor, cfg: TtaConfig, dtype=torch.float32):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.text0 = text_kd.to(dtype).clone()
+        self.st = gmm_init(text_kd, cfg.num_modes, cfg.sigma, cfg.epsilon, dtype)
+        self.res = torch.zeros_like(self.text0)
+        self.adam = AdamState(torch.zeros_like(self.text0), torch.zeros_like(self.text0))
+        self.i = 0
+        self.last_loss = None
+
+    def step(self, feat: torch.Tensor, feat_aug: torch.Tensor):
+        cfg = self.cfg
+        text = current_text(self.text0, self.res if cfg.res_learning else None)     # :388-401
+        f, z, ent, prob, pred = clip_logits(feat.to(self.dtype), text)              # :406
+        xq = f.mean(0)[None].half()                                                 # :416
+        dz = gmm_predict(self.st, xq)
+        gmm_fit(self.st, f, prob)                                                   # :417
+        fa, _, _, _, _ = clip_logits(feat_aug.to(self.dtype), text)                 # :424
+        fa = fa / fa.norm(dim=-1, keepdim=True)                                     # :429
+        gmm_fit(self.st, fa, prob)                                                  # :430
+        if self.i > 0 and cfg.res_learning:                                         # :444-476
+            self.last_loss, _ = residual_learning(self.st, self.text0, self.res, self.adam,
+                                                  cfg.res_steps)
+        final = fuse_logits(z, dz, self.st.c, cfg.rho, cfg.eta, batch=f.shape[0])   # :491-521
+        self.i += 1
+        return z, dz, final, int(pred[0])

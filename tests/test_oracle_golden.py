@@ -1,0 +1,176 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) to the golden vectors produced by RUNNING the
+reference (oracle/make_golden.py).  CPU-only; no HIP involved."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+torch.set_num_threads(1)
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize('name', ['modelnet40', 'scanobjectnn', 'shapenet55'])
+def test_g1_init_matches_reference(golden_dir, name):
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    st = O.gmm_init(_t(g['text']), int(g['M']), 1e-4, 1e-4)
+    assert torch.equal(st.pi, _t(g['init_pi']))
+    assert torch.equal(st.c, _t(g['init_c']))
+    assert torch.equal(st.mu[:, :, :16], _t(g['init_mu_head']))
+    assert torch.equal(st.var[:, :, :16], _t(g['init_var_head']))
+    assert float(st.mu.double().sum()) == float(g['init_mu_sum'])
+    assert float(st.var.double().sum()) == float(g['init_var_sum'])
+
+
+def test_g1_sigma_autocorrect(golden_dir):
+    g = _load(golden_dir, 'g1_init_sigma_autocorrect.npz')
+    st = O.gmm_init(_t(g['text']), 3, 1.0, 1e-3)
+    assert torch.equal(st.mu[:, :, :8], _t(g['mu_head']))
+    assert torch.equal(st.var[:, :, :8], _t(g['var_head']))
+    assert torch.equal(st.pi, _t(g['pi'])) and torch.equal(st.c, _t(g['c']))
+
+
+@pytest.mark.parametrize('name', ['modelnet40', 'scanobjectnn', 'shapenet55'])
+def test_g2_stream_matches_reference_loop(golden_dir, name):
+    """Whole --use-mode-dota loop body incl. residual learning; the oracle uses the same torch
+    ops in the same order, so it reproduces the reference to float round-off (bit-exact for the
+    cache part; residual learning goes through autograd whose reduction order we do not control,
+    hence the small tolerance)."""
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    cfg = O.TtaConfig(num_modes=int(g['M']))
+    s = O.TtaStream(_t(g['text']), cfg)
+    n = g['feat'].shape[0]
+    for i in range(n):
+        z, dz, final, pred = s.step(_t(g['feat'][i:i + 1]), _t(g['feat_aug'][i:i + 1]))
+        assert pred == int(g['pred'][i]), i
+        np.testing.assert_allclose(z[0].numpy(), g['clip'][i], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(dz[0].numpy(), g['dota_raw'][i], rtol=0, atol=4e-3)
+        np.testing.assert_allclose(final[0].numpy(), g['final'][i], rtol=0, atol=1e-3)
+        assert int(final.argmax()) == int(np.argmax(g['final'][i]))
+        if i in g['snap_steps']:
+            np.testing.assert_allclose(s.st.c.numpy(), g[f'snap{i}_c'], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(s.st.pi.numpy(), g[f'snap{i}_pi'], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(s.res[:, :32].numpy(), g[f'snap{i}_res_head'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(s.st.mu[:, :, :16].numpy(), g['end_mu_head'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(s.st.var[:, :, :16].numpy(), g['end_var_head'], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(s.st.class_counts.numpy(), g['end_class_counts'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.res.numpy(), g['end_res'], rtol=0, atol=5e-5)
+
+
+def test_g2_first_step_is_bit_exact(golden_dir):
+    """Before residual learning starts (i == 0) the path has no autograd: bit-exact."""
+    g = _load(golden_dir, 'g2_stream_modelnet40.npz')
+    s = O.TtaStream(_t(g['text']), O.TtaConfig(num_modes=int(g['M'])))
+    z, dz, final, pred = s.step(_t(g['feat'][0:1]), _t(g['feat_aug'][0:1]))
+    assert np.array_equal(z[0].numpy(), g['clip'][0])
+    assert np.array_equal(dz[0].numpy(), g['dota_raw'][0])
+    assert np.array_equal(final[0].numpy(), g['final'][0])
+    assert np.array_equal(s.st.c.numpy(), g['snap0_c'])
+
+
+def test_g2b_batched_fit_bit_exact(golden_dir):
+    g = _load(golden_dir, 'g2b_batched_fit.npz')
+    st = O.gmm_init(_t(g['text']), int(g['M']), 1e-4, 1e-4)
+    for i in range(6):
+        z = O.gmm_predict(st, _t(g[f'x{i}']).half())
+        assert np.array_equal(z.numpy(), g[f'z{i}'])
+        O.gmm_fit(st, _t(g[f'x{i}']), _t(g[f'g{i}']))
+    for k in ('mu', 'var', 'c', 'pi', 'class_counts'):
+        assert np.array_equal(getattr(st, k).numpy(), g['end_' + k]), k
+    assert st.t == int(g['end_t'])
+
+
+def test_g3_alignment_loss_matrix_and_grad(golden_dir):
+    g = _load(golden_dir, 'g3_alignment_scanobjectnn.npz')
+    K, M = g['pi'].shape
+    st = O.GmmState(_t(g['mu']), _t(g['var']), _t(g['pi']), _t(g['c']), torch.zeros(K), float(g['eps']))
+    text0, res = _t(g['text']), _t(g['res']).clone().requires_grad_(True)
+    t = text0 + res
+    e = t / t.norm(dim=1, keepdim=True)
+    L = O.alignment_matrix(st, e)
+    loss = O.alignment_loss_from_matrix(L)
+    (gr,) = torch.autograd.grad(loss, res)
+    np.testing.assert_allclose(L.detach().numpy(), g['L'], rtol=0, atol=2e-3)
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    np.testing.assert_allclose(gr.numpy(), g['grad_res'], rtol=1e-3, atol=1e-7)
+    # the docstring property at Uni_Adapter.py:205-206: row i == predict(e_i)
+    np.testing.assert_allclose(O.gmm_predict(st, e[3:4].detach()).numpy(), g['predict_row3'], atol=2e-3)
+    np.testing.assert_allclose(L[3].detach().numpy(), g['predict_row3'][0], atol=2e-3)
+    # closed-form dLoss/dL used by the HIP kernel == autograd
+    Ld = L.detach().double().requires_grad_(True)
+    (Ga,) = torch.autograd.grad(O.alignment_loss_from_matrix(Ld), Ld)
+    loss2, G = O.alignment_loss_grad(L.detach().double())
+    np.testing.assert_allclose(G.numpy(), Ga.numpy(), rtol=1e-9, atol=1e-15)
+    assert abs(float(loss2) - float(loss)) < 1e-6
+
+
+def test_g4_fusion_known_answers(golden_dir):
+    g = _load(golden_dir, 'g4_fusion.npz')
+    for i in range(int(g['n'])):
+        out = O.fuse_logits(_t(g[f'clip{i}']), _t(g[f'dota{i}']), _t(g[f'c{i}']), 0.02, 0.1, batch=1)
+        assert np.array_equal(out.numpy(), g[f'final{i}']), i
+
+
+def test_g5_grouping(golden_dir):
+    g = _load(golden_dir, 'g5_group.npz')
+    xyz, rgb, cidx = _t(g['xyz']), _t(g['rgb']), _t(g['center_idx'])
+    center, feat, idx = O.group_points(xyz, rgb, cidx, 32)
+    assert np.array_equal(idx.numpy(), g['idx_sorted'])
+    sq = O.square_distance(center, xyz)
+    assert np.array_equal(sq[:, :4].numpy(), g['sqdist_rows'])
+    np.testing.assert_allclose(feat.double().sum(2).numpy(), g['feat_sorted_sum'], rtol=0, atol=1e-6)
+
+
+def test_g6_patch_encoder(golden_dir):
+    g = _load(golden_dir, 'g6_patch_encoder.npz')
+    sd = O.make_uni3d_state_dict(int(g['weights_seed']), trans_dim=64, embed_dim=32, enc_dim=512, depth=0)
+    for k, v in g.items():
+        if k.startswith('w_'):      # RNG reproducibility of the synthetic weights
+            assert np.array_equal(sd['point_encoder.encoder.' + k[2:]].numpy(), v), k
+    tok = O.patch_encoder(_t(g['feat']), sd, 'point_encoder.encoder.')
+    np.testing.assert_allclose(tok.numpy(), g['tokens'], rtol=1e-4, atol=1e-5)
+
+
+def test_g7_fps_pure_torch_flavour(golden_dir):
+    g = _load(golden_dir, 'g7_fps.npz')
+    xyz = _t(g['xyz'])
+    idx = O.fps(xyz, 64, start=int(g['start']), skip_origin_eps=-1.0)
+    assert np.array_equal(xyz[0, idx[0]].numpy(), g['centers'][0])
+
+
+def test_adam_restatement_matches_torch_optim():
+    torch.manual_seed(0)
+    p = torch.randn(5, 16)
+    q = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([q], lr=1e-3)
+    a = O.AdamState(torch.zeros_like(p), torch.zeros_like(p))
+    for _ in range(25):
+        gr = torch.randn(5, 16) * 10 ** float(torch.randint(-6, 2, (1,)))
+        q.grad = gr.clone()
+        opt.step()
+        O.adam_step(p, gr, a)
+    assert torch.equal(p, q.detach())
+
+
+def test_properties():
+    torch.manual_seed(1)
+    text = torch.nn.functional.normalize(torch.randn(9, 256), dim=1)
+    st = O.gmm_init(text, 4, 1e-4, 1e-4)
+    x = torch.nn.functional.normalize(text[2:3] + 0.05 * torch.randn(1, 256), dim=1)
+    O.gmm_fit(st, x, torch.softmax(100 * x @ text.T, 1))
+    before = st.clone()
+    O.gmm_fit(st, x, torch.zeros(1, 9))                 # gamma == 0 leaves the state unchanged
+    for k in ('mu', 'var', 'c'):
+        np.testing.assert_allclose(getattr(st, k).numpy(), getattr(before, k).numpy(), rtol=1e-6, atol=1e-10)
+    perm = torch.tensor([2, 0, 3, 1])                   # predict is invariant to mode order
+    st2 = O.GmmState(st.mu[:, perm], st.var[:, perm], st.pi[:, perm], st.c[:, perm], st.class_counts, st.epsilon)
+    np.testing.assert_allclose(O.gmm_predict(st, x).numpy(), O.gmm_predict(st2, x).numpy(), atol=2e-3)
