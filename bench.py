@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py - whole-job throughput of the per-sample test-time hot path on N x MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Uni3D-L encoder (1024-d, 24 EVA02 blocks, 16 heads, SwiGLU
+2730, 512 groups x 64 points) + MODE-DOTA (K=40 ModelNet40 text bank, M=8, residual learning on),
+synthetic 1024-point clouds, random-init weights of that architecture, fp32 end to end.
+One STEP = one chunk of `--chunk` samples PER RANK through the full loop body of
+Uni_Adapter.py:368-579: 2 encoder forwards per sample (original + augmented cloud), clip logits,
+predict + 2 fits, 10 Adam steps of residual learning, fusion.  Inputs are resident in HBM when
+the timed region starts.  value = point clouds (samples) per second over all ranks.
+
+The JSON line also carries
+  roofline      - the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches in the
+                  timed region / their summed HIP-event durations, vs the 157.3 TFLOP/s fp32 MFMA peak
+  similarity    - the cache "similarity kernel" (ua_gmm_loglik, BASELINE.json configs[4] shape
+                  K=4096, M=16, D=1024, fp32) and the fused predict+fit+fit pass vs the 8 TB/s HBM peak
+  cpu_baseline  - the CPU oracle (PyTorch-CPU restatement, kind "port") on the host cores, on a
+                  bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--chunk', type=int, default=16, help='samples per rank per step')
+    ap.add_argument('--depth', type=int, default=24)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-similarity', action='store_true')
+    ap.add_argument('--cpu-samples', type=int, default=4)
+    ap.add_argument('--no-res-learning', action='store_true')
+    return ap.parse_args()
+
+
+def similarity_roofline(dev):
+    """HBM roofline of the similarity kernel at configs[4] size (state 2 x 268 MB > Infinity Cache)."""
+    from uni_adapter_amd import lib
+    K, M, D = 4096, 16, 1024
+    g = torch.Generator(device=dev).manual_seed(0)
+    mu = torch.randn(K, M, D, device=dev, generator=g) * 0.03
+    var = 1e-4 * (1 + torch.rand(K, M, D, device=dev, generator=g))
+    pi = torch.full((K, M), 1.0 / M, device=dev); c = torch.full((K, M), 1.0 / M, device=dev)
+    cc = torch.zeros(K, device=dev)
+    x = torch.nn.functional.normalize(torch.randn(1, D, device=dev, generator=g), dim=1)
+    gam = torch.softmax(torch.randn(1, K, device=dev, generator=g), 1)
+    scores = torch.empty(1, K, device=dev)
+    st = lib.stream_ptr()
+
+    def predict():
+        lib.call('ua_gmm_loglik', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(x), 1, K, M, D, 1e-4, lib.ptr(scores), None, None, st)
+
+    def fused():
+        lib.call('ua_gmm_step_fused', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(c), lib.ptr(cc), lib.ptr(x), 1, lib.ptr(x),
+                 lib.ptr(x), lib.ptr(gam), lib.ptr(scores), K, M, D, 1e-4, st)
+
+    out = {}
+    for name, fn, nbytes in (('predict', predict, 2.0 * K * M * D * 4), ('fused_step', fused, 4.0 * K * M * D * 4)):
+        for _ in range(3):
+            fn()
+        evs = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                     'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': nbytes,
+                     'ms_per_launch': round(ms, 4), 'shape': {'K': K, 'M': M, 'D': D, 'dtype': 'f32'}}
+    return out
+
+
+def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
+    """Oracle (kind 'port') timed on the host cores on the first n samples of the same stream."""
+    from oracle import ref_cpu as O               # baseline leg only
+    torch.set_num_threads(os.cpu_count())
+    s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
+    enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
+    t_enc = t_cache = 0.0
+    with torch.no_grad():
+        enc(torch.cat([xyz[:1], rgb[:1]], -1))     # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for i in range(n):
+        a = time.perf_counter()
+        with torch.no_grad():
+            f = enc(torch.cat([xyz[i:i + 1], rgb[i:i + 1]], -1))
+            fa = enc(torch.cat([xyz[i:i + 1] + 0.05 * noise[i:i + 1], rgb[i:i + 1]], -1))
+        b = time.perf_counter()
+        s.step(f, fa)
+        t_enc += b - a; t_cache += time.perf_counter() - b
+    dt = time.perf_counter() - t0
+    return {'value': round(n / dt, 4), 'unit': 'point-clouds/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'first {n} samples of the same synthetic stream (2 encoder forwards + cache step + residual learning each); '
+                      f'encoder {t_enc / n:.2f} s/sample, cache+residual {t_cache / n:.2f} s/sample'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)'
+
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd import point_encoder as PE, synthetic
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+
+    cfg = dict(G=512, S=64, heads=16, M=8, res=not a.no_res_learning)
+    # real ModelNet40 text bank (K=40, D=1024) ships as fixture data; weights are random-init
+    gpath = os.path.join(ROOT, 'tests', 'golden', 'g2_stream_modelnet40.npz')
+    text = torch.from_numpy(np.load(gpath)['text']) if os.path.exists(gpath) else synthetic.text_bank(40, 1024)
+    sd = synthetic.uni3d_state_dict(0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=a.depth, device=dev)
+    model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev)
+    n_local, n_global = a.chunk, a.chunk * world
+    total_steps = a.warmup + a.steps
+    # the whole synthetic stream is resident in HBM before the timed region (same stream on every rank)
+    xyz, rgb = synthetic.point_clouds(n_global * total_steps, 1024, seed=42, device=dev)
+    noise = torch.randn(xyz.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
+                    chunk=n_global, device=dev)
+
+    def step(i):
+        s = slice(i * n_global, (i + 1) * n_global)
+        return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    prof = PE.GemmProfiler()
+    fence()
+    PE.PROFILER = prof
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total_steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    PE.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    samples = n_global * a.steps
+    gsum = prof.summary()
+    tfl = gsum['flops'] / (gsum['ms'] * 1e-3) / 1e12 if gsum['ms'] > 0 else 0.0
+    out = {
+        'metric': 'point-clouds/sec (1024 pts), Uni3D-L + MODE-DOTA M=8 test-time stream (ModelNet40-C shaped)',
+        'value': round(samples / dt, 3), 'unit': 'point-clouds/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'Uni3D-L encoder x2 forwards/sample + MODE-DOTA cache step (K=40, M=8, D=1024, residual learning '
+                               + ('on' if cfg['res'] else 'off') + ') on synthetic 1024-pt clouds; BASELINE.json configs[1]',
+                   'samples_per_rank_per_step': n_local, 'global_samples_per_step': n_global, 'encoder_depth': a.depth,
+                   'parallelism': f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step'},
+        'roofline': {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(tfl / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_f32_mfma_kernel',
+                     'launches': gsum['launches'], 'flops_per_launch_avg': gsum['flops'] / max(1, gsum['launches']),
+                     'ms_per_launch_avg': round(gsum['ms'] / max(1, gsum['launches']), 5),
+                     'gemm_share_of_step_time': round(gsum['ms'] * 1e-3 / dt, 4)},
+    }
+    if rank == 0 and not a.no_similarity:
+        out['similarity'] = similarity_roofline(dev)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+        n = a.cpu_samples
+        out['cpu_baseline'] = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

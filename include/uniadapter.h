@@ -1,0 +1,187 @@
+/*
+ * uniadapter.h - C ABI of libuniadapter_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the Uni-Adapter per-sample test-time hot path.  The reference has no
+ * FFI of its own (it is pure Python on PyTorch); the seams it does have are Python duck-typed
+ * call sites, cited per entry point below as `file:line` under the reference root.  Every entry
+ * point here is what a binding for that call site would bind (see INTEGRATION.md for the ctypes
+ * stubs).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch / C++ types in any signature
+ *   - return 0 (UA_OK) or a negative UA_E* code; no exception crosses the ABI; ua_strerror(code)
+ *   - every buffer (inputs, outputs, state, workspace) is owned by the caller and must stay alive
+ *     until the stream reaches the enqueued work; the library never allocates, frees or keeps
+ *     pointers, has no global mutable state and never synchronises the device
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *   - tensors are row-major, contiguous unless a leading dimension (ld*) is given, fp32 unless
+ *     stated; pointers must be 16-byte aligned, feature dims multiples of 4
+ *   - GMM state layout: mu,var (K,M,D) with D fastest; pi,c (K,M); class_counts (K)
+ */
+#ifndef UNIADAPTER_H
+#define UNIADAPTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UA_OK             0
+#define UA_EINVAL        -1   /* null pointer / non-positive or inconsistent shape            */
+#define UA_EALIGN        -2   /* pointer or leading dimension not 16-byte aligned             */
+#define UA_EUNSUPPORTED  -3   /* shape outside the compiled envelope (see each function)      */
+#define UA_EWORKSPACE    -4   /* workspace too small                                          */
+#define UA_ELAUNCH       -5   /* hipGetLastError() != hipSuccess after the launch             */
+
+#define UA_VERSION 100        /* 0.1.0 */
+
+int         ua_version(void);
+const char* ua_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * MODE-DOTA cache (reference class DOTA_mix, dota_mixture.py:7-274)
+ * Envelope of the register-resident kernels: D % 256 == 0, D <= 2048, 1 <= M <= 16.
+ * ------------------------------------------------------------------------------------------ */
+
+/* DOTA_mix.predict (dota_mixture.py:236-267) + _log_likelihood (:121-156) for B queries:
+ *   v = max(var+eps,1e-8); ll[b,k,m] = -1/2 (sum_d ln v + sum_d (x-mu)^2/v)
+ *   joint = ln(pi+1e-10) + ll ; scores[b,k] = logsumexp_m joint
+ * Any of scores (B,K), joint (B,K,M), loglik (B,K,M) may be NULL.  Also the batched forward of
+ * compute_text_alignment_loss (Uni_Adapter.py:219-244) with x = class embeddings (B = K).      */
+int ua_gmm_loglik(const float* mu, const float* var, const float* pi, const float* x,
+                  int32_t B, int32_t K, int32_t M, int32_t D, float eps,
+                  float* scores, float* joint, float* loglik, void* stream);
+
+/* Gradient of sum(grad_ll * loglik) w.r.t. x: the backward that autograd takes through
+ * DOTA_mix._log_likelihood in Uni_Adapter.py:228,467-469.  grad_ll (B,K,M) -> grad_x (B,D).    */
+int ua_gmm_loglik_bwd(const float* mu, const float* var, const float* x, const float* grad_ll,
+                      int32_t B, int32_t K, int32_t M, int32_t D, float eps,
+                      float* grad_x, void* stream);
+
+/* DOTA_mix.fit (dota_mixture.py:162-234): one streaming-EM step, state updated in place.
+ * x (B,D), gamma_class (B,K); B <= 64.                                                         */
+int ua_gmm_fit(float* mu, float* var, float* pi, float* c, float* class_counts,
+               const float* x, const float* gamma_class,
+               int32_t B, int32_t K, int32_t M, int32_t D, float eps, void* stream);
+
+/* The cache step of one test sample in ONE pass over the state (Uni_Adapter.py:416-430):
+ *   scores = predict(fp16-rounded xq) ; fit(x1, gamma) ; fit(x2, gamma)
+ * xq,x1,x2 (1,D); gamma (1,K); scores (1,K).  xq_round_fp16 != 0 applies the `.half()` of
+ * Uni_Adapter.py:416 to xq inside the kernel.                                                  */
+int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_counts,
+                      const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                      const float* gamma_class, float* scores,
+                      int32_t K, int32_t M, int32_t D, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Zero-shot logits and fusion (Uni_Adapter.py)
+ * ------------------------------------------------------------------------------------------ */
+
+/* get_logits_wrapper (Uni_Adapter.py:53-75), uni3d branch, batch 1, given the encoder output:
+ *   fhat = feat/|feat| (applied `n_normalize` times: 1 for :56, 2 for :56 followed by :429)
+ *   logits = (scale*fhat) @ text^T ; prob = softmax ; entropy = -sum p ln(p+1e-10) ; pred=argmax
+ * text is the CURRENT (K,D) text matrix (the reference holds its transpose).
+ * Outputs (any may be NULL): fhat (D), logits (K), prob (K), entropy (1), pred (1, int32).     */
+int ua_clip_logits(const float* feat, const float* text, int32_t K, int32_t D, float scale,
+                   int32_t n_normalize, float* fhat, float* logits, float* prob, float* entropy,
+                   int32_t* pred, void* stream);
+
+/* Entropy-weighted fusion (Uni_Adapter.py:491-521 incl. the weight-reuse quirk at :512-513):
+ *   w = min(rho*mean(c)/batch, eta); d = w*dota; wc=1/(H(clip)+1e-3); wd=1/(H(d)+1e-3);
+ *   wc = wc/(wc+wd); wd = wd/(wc+wd); final = wc*clip + wd*d
+ * Optionally (target != NULL) writes rank = #classes with final > final[target] (top-k
+ * accuracy, utils/utils.py:154-167) and the arg-max.                                           */
+int ua_fuse_logits(const float* clip_logits, const float* dota_logits, const float* c,
+                   int32_t K, int32_t M, float rho, float eta, int32_t batch,
+                   const int32_t* target, float* final_logits, int32_t* rank, int32_t* pred,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Residual learning of the text anchors (Uni_Adapter.py:191-270, 444-476)
+ * ------------------------------------------------------------------------------------------ */
+
+/* e = (text0+res)/|text0+res| per row (Uni_Adapter.py:388-393, 451-456); norm_out (K) optional.
+ * clamp_eps: F.normalize's max(|t|,eps) (1e-12 at :392) or 0 for the plain division at :456.   */
+int ua_text_normalize(const float* text0, const float* res, int32_t K, int32_t D, float clamp_eps,
+                      float* e_out, float* norm_out, void* stream);
+
+/* Loss of compute_text_alignment_loss (Uni_Adapter.py:248-253) from L (K,K) and its closed-form
+ * gradient pushed through logsumexp_m: grad_ll[i,k,m] = dLoss/dL[i,k] * exp(joint[i,k,m]-L[i,k]).
+ * K <= 160.  loss_out (1), grad_ll (K,K,M).                                                    */
+int ua_align_loss(const float* L, const float* joint, int32_t K, int32_t M,
+                  float* loss_out, float* grad_ll, void* stream);
+
+/* Chain grad_e through e = t/|t| (t = text0+res), apply one torch.optim.Adam step
+ * (lr, betas, eps as Uni_Adapter.py:350-352; `step` is the 1-based step count) to res and its
+ * moments, then refresh e and norm for the next evaluation.  All (K,D) except norm (K).        */
+int ua_residual_adam(const float* text0, float* res, float* adam_m, float* adam_v,
+                     const float* grad_e, float* e, float* norm,
+                     int32_t K, int32_t D, int32_t step, double lr, double beta1, double beta2,
+                     double adam_eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Uni3D point-cloud encoder (models/point_encoder.py, models/uni3d.py, timm EVA02 blocks)
+ * ------------------------------------------------------------------------------------------ */
+
+/* fps (models/point_encoder.py:7-14 -> pointnet2_ops furthest_point_sample + gather).
+ * xyz (B,N,3); N <= 4096.  start: first index (0 = pointnet2 convention); skip_eps >= 0 skips
+ * points with |p|^2 <= skip_eps as the pointnet2 CUDA kernel does (1e-3), < 0 disables.
+ * Ties go to the lowest index.  center_idx (B,G) int32 (optional), centers (B,G,3).            */
+int ua_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int32_t start, float skip_eps,
+           int32_t* center_idx, float* centers, void* stream);
+
+/* knn_point + Group.forward (models/point_encoder.py:17-49, 99-127): the S nearest points of
+ * every centre under the expanded-form distance -2c.p+|c|^2+|p|^2, gathered as
+ * [xyz - centre, rgb].  feat (B*G*S, ldf) with ldf >= 6 (columns 6..ldf-1 are zero-filled);
+ * idx (B,G,S) int32 optional (ascending index order inside a group).  N <= 4096, S <= 256.     */
+int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
+                 int32_t B, int32_t N, int32_t G, int32_t S,
+                 float* feat, int32_t ldf, int32_t* idx, void* stream);
+
+/* Epilogue of ua_gemm; all pointers optional (NULL = skipped).  Order of operations:
+ *   v = acc + bias[n] + rowgroup_add[m / group_rows, n]
+ *   v = v*scale[n] + shift[n]                (eval BatchNorm, models/point_encoder.py:135,141)
+ *   act: 0 none | 1 ReLU | 2 GELU(erf) | 3 SwiGLU (columns come in blocks of 32 gate / 32 up:
+ *        out[:, j] = silu(gate)*up, N_out = N/2; timm SwiGLU of EvaBlock)
+ *   v += residual[m, n]
+ *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64)    */
+typedef struct {
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const float* rowgroup_add; int64_t ldg; int32_t group_rows;
+    int32_t      act;
+    const float* residual;     int64_t ldr;
+    float*       pool_out;     int64_t ldp; int32_t pool_rows;
+} ua_gemm_epilogue;
+
+/* C (M,N) = A (M,K) @ W (N,K)^T with fused epilogue: every Linear / Conv1d(k=1) of the encoder
+ * (models/point_encoder.py:133-144,175-186; timm EvaBlock q/k/v/proj/fc1/fc2).  fp32 inputs,
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  K % 4 == 0; lda, ldw, ldc % 4 == 0.               */
+int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+            int32_t M, int32_t N, int32_t K, const ua_gemm_epilogue* ep, void* stream);
+
+/* LayerNorm over the last dim (timm LayerNorm eps 1e-6): rows x cols, cols % 4 == 0, cols<=8192.
+ * Columns cols..cols_pad-1 of y are zero-filled (GEMM K padding).                              */
+int ua_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                 float* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad, void* stream);
+
+/* Multi-head self-attention softmax(q k^T / sqrt(hd)) v of timm EvaAttention without rope
+ * (models/point_encoder.py:217-218) for Bc clouds of G patch tokens + 1 CLS token.
+ * Token rows: cloud b patch g -> b*G+g ; CLS of cloud b -> Bc*G+b.  qkv (rows, 3*H*hd) with
+ * q|k|v column blocks; out (rows, H*hd).  hd == 64.                                            */
+int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                 int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
+
+/* Token assembly (models/point_encoder.py:198-208): x[b*G+g] = tok[b*G+g] + pos[b*G+g];
+ * x[Bc*G+b] = cls_token + cls_pos.                                                             */
+int ua_assemble_tokens(const float* tok, const float* pos, const float* cls_token,
+                       const float* cls_pos, float* x, int32_t Bc, int32_t G, int32_t C,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIADAPTER_H */

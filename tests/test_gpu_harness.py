@@ -1,0 +1,131 @@
+"""GPU parity of the whole per-sample loop (uni_adapter_amd.Uni_Adapter) against (a) the golden
+streams produced by the reference's own loop body and (b) the CPU oracle end to end."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+class FeatureFeeder(torch.nn.Module):
+    """Stands in for the encoder exactly like the golden generator did: returns queued features."""
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = feats          # (n,2,D) device
+        self.pos = 0
+
+    def encode_pc(self, clouds):
+        n2 = clouds.shape[0]
+        out = self.feats.view(-1, self.feats.shape[-1])[self.pos:self.pos + n2]
+        self.pos += n2
+        return out.contiguous()
+
+
+@pytest.mark.parametrize('name,chunk', [('modelnet40', 16), ('scanobjectnn', 5), ('shapenet55', 1)])
+def test_loop_with_residual_learning_vs_reference_golden(golden_dir, name, chunk):
+    """The full --use-mode-dota loop (clip logits, predict, fit x2, 10-step residual learning,
+    fusion) on the HIP path, fed with the golden encoder outputs, against what the reference's loop
+    body produced on the same stream.  North-star bar: predictions identical, final logits 1e-3."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    text = torch.from_numpy(g['text'])
+    n = g['feat'].shape[0]
+    feats = torch.stack([torch.from_numpy(g['feat']), torch.from_numpy(g['feat_aug'])], 1).cuda()
+    model = FeatureFeeder(feats)
+    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, int(g['M']), res_learning=True, chunk=chunk)
+    finals, preds = [], []
+    pc = torch.zeros(n, 8, 3); rgb = torch.ones(n, 8, 3)
+    tgt = torch.from_numpy(g['labels']).int()
+    for s in range(0, n, chunk):
+        f, r, p = eng.process_chunk(pc[s:s + chunk], rgb[s:s + chunk], tgt[s:s + chunk])
+        finals.append(f.cpu()); preds.append(p.cpu())
+    final = torch.cat(finals).numpy(); pred = torch.cat(preds).numpy()
+    ref_pred = g['final'].argmax(1)
+    assert np.array_equal(pred, ref_pred)
+    err = np.abs(final - g['final']).max(1)
+    # per-sample error profile is printed for DESIGN.md; the bar itself is 1e-3
+    print(name, 'max |dlogit| per step:', np.round(err, 6).tolist())
+    assert err.max() <= 1e-3, err.max()
+    np.testing.assert_allclose(eng.residuals.res.cpu().numpy(), g['end_res'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(eng.mode_dota_model.c.cpu().numpy(), g['end_c'], rtol=1e-4, atol=1e-6)
+    acc = eng.accuracy()
+    want1 = 100.0 * float((ref_pred == g['labels']).mean())
+    assert abs(acc['acc1'] - want1) < 1e-9
+
+
+def test_end_to_end_vs_oracle_with_encoder():
+    """test_zeroshot_3d_core (reference signature) with the HIP encoder + cache on a synthetic
+    stream, against the oracle running the same clouds, noise and weights on the CPU."""
+    from uni_adapter_amd.Uni_Adapter import test_zeroshot_3d_core
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    K, D, G, n = 12, 256, 128, 7
+    sd = O.make_uni3d_state_dict(21, trans_dim=128, embed_dim=D, enc_dim=512, depth=2)
+    g = torch.Generator().manual_seed(1)
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    xyz = torch.randn(n, 1024, 3, generator=g); xyz = xyz / xyz.norm(dim=-1, keepdim=True).amax(1, keepdim=True)
+    rgb = torch.ones(n, 1024, 3)
+    noise = torch.randn(n, 1024, 3, generator=g)
+    labels = torch.randint(0, K, (n,), generator=g)
+    model = create_uni3d_from_state_dict(sd, num_group=G, group_size=64, num_heads=2)
+    args = SimpleNamespace(use_mode_dota=True, res_learning=True, dota_epsilon=1e-4, dota_sigma=1e-4, dota_eta=0.1, dota_rho=0.02,
+                           mode_M=4, device='cuda:0', precomputed_text_features=text, chunk_size=3, print_freq=0,
+                           aug_noise=lambda i, pc: noise[i:i + 1], vlm3d='uni3d')
+    loader = [(xyz[i:i + 1], labels[i:i + 1], ['x'], rgb[i:i + 1]) for i in range(n)]
+    acc = test_zeroshot_3d_core(loader, 'synthetic', model, None, None, args, {})
+    # oracle
+    s = O.TtaStream(text, O.TtaConfig(num_modes=4))
+    hits = np.zeros(3)
+    for i in range(n):
+        pc6 = torch.cat([xyz[i:i + 1], rgb[i:i + 1]], -1)
+        pc6a = torch.cat([xyz[i:i + 1] + 0.05 * noise[i:i + 1], rgb[i:i + 1]], -1)
+        f = O.uni3d_encode_pc(pc6, sd, G, 64, 2)
+        fa = O.uni3d_encode_pc(pc6a, sd, G, 64, 2)
+        z, dz, final, pred = s.step(f, fa)
+        a = O.accuracy_topk(final, labels[i:i + 1])
+        hits += np.array(a) / 100.0
+    for k, v in zip(('acc1', 'acc3', 'acc5'), hits / n * 100.0):
+        assert abs(acc[k] - v) < 1e-9, (k, acc[k], v)
+
+
+def test_chunking_does_not_change_results(golden_dir):
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = _load(golden_dir, 'g2_stream_scanobjectnn.npz')
+    text = torch.from_numpy(g['text']); n = 12
+    feats = torch.stack([torch.from_numpy(g['feat'][:n]), torch.from_numpy(g['feat_aug'][:n])], 1).cuda()
+    outs = []
+    for chunk in (1, 4, 12):
+        eng = TtaEngine(FeatureFeeder(feats), text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 8, chunk=chunk)
+        fs = [eng.process_chunk(torch.zeros(min(chunk, n - s), 8, 3), torch.ones(min(chunk, n - s), 8, 3))[0].cpu() for s in range(0, n, chunk)]
+        outs.append(torch.cat(fs))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_compute_text_alignment_loss_api(golden_dir):
+    from uni_adapter_amd.Uni_Adapter import compute_text_alignment_loss
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    g = _load(golden_dir, 'g3_alignment_scanobjectnn.npz')
+    K, M = g['pi'].shape; D = g['mu'].shape[2]
+    text = torch.from_numpy(g['text'])
+    mdl = DOTA_mix({'epsilon': float(g['eps']), 'sigma': 1e-4}, D, K, text.T, num_modes=M)
+    mdl.mu.copy_(torch.from_numpy(g['mu'])); mdl.var.copy_(torch.from_numpy(g['var'])); mdl.pi.copy_(torch.from_numpy(g['pi']))
+    res = torch.from_numpy(g['res']).cuda().requires_grad_(True)
+    t = text.cuda() + res
+    e = t / t.norm(dim=1, keepdim=True)
+    loss, L = compute_text_alignment_loss(e, mdl)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 2e-6
+    np.testing.assert_allclose(L.detach().cpu().numpy(), g['L'], rtol=0, atol=3e-3)
+    ref = torch.from_numpy(g['grad_res'])
+    assert (res.grad.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # property stated in the reference docstring (Uni_Adapter.py:205-206)
+    row = mdl.predict(e[3:4].detach())
+    np.testing.assert_allclose(row.cpu().numpy()[0], L[3].detach().cpu().numpy(), rtol=0, atol=1e-3)

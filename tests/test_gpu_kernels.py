@@ -1,0 +1,418 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C ABI
+(ctypes), against the CPU oracle on the same seeded inputs and against the golden fixtures."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as O
+
+
+@pytest.fixture(scope='module')
+def ua():
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd import lib
+    return lib
+
+
+_KEEP = []
+
+
+def dev(t, dtype=torch.float32):
+    """Host -> device copy that stays alive until the end of the test (the C ABI takes raw
+    pointers, so a temporary freed right after `.data_ptr()` would be recycled by the allocator)."""
+    d = t.to('cuda', dtype).contiguous()
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _stream_state(K, M, D, n_fit, seed):
+    """A non-trivial GMM state: oracle init + n_fit streaming updates."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    st = O.gmm_init(text, M, 1e-4, 1e-4)
+    for _ in range(n_fit):
+        lab = torch.randint(0, K, (1,), generator=g)
+        x = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(1, D, generator=g), dim=1)
+        O.gmm_fit(st, x, torch.softmax(100 * x @ text.T, 1))
+    return text, st, g
+
+
+def _as64(st):
+    return O.GmmState(st.mu.double(), st.var.double(), st.pi.double(), st.c.double(),
+                      st.class_counts.double(), st.epsilon, st.t)
+
+
+# ------------------------------------------------------------------ cache kernels
+@pytest.mark.parametrize('K,M,D,B', [(40, 8, 1024, 1), (15, 4, 512, 3), (7, 16, 1280, 33), (55, 1, 256, 2), (3, 3, 2048, 1)])
+def test_gmm_loglik_matches_oracle(ua, K, M, D, B):
+    text, st, g = _stream_state(K, M, D, 20, 1)
+    x = torch.nn.functional.normalize(text[torch.randint(0, K, (B,), generator=g)] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+    scores = torch.empty(B, K, device='cuda'); joint = torch.empty(B, K, M, device='cuda'); ll = torch.empty(B, K, M, device='cuda')
+    ua.call('ua_gmm_loglik', ua.ptr(dev(st.mu)), ua.ptr(dev(st.var)), ua.ptr(dev(st.pi)), ua.ptr(dev(x)),
+            B, K, M, D, st.epsilon, ua.ptr(scores), ua.ptr(joint), ua.ptr(ll), ua.stream_ptr())
+    ref64 = O.gmm_predict(_as64(st), x.double())
+    ref32 = O.gmm_predict(st, x)
+    # Raw scores are ~3e3..7e3 with a ~9e3 log-det inside (fp32 ulp 5e-4..1e-3).  The kernel sums in
+    # fp64 but takes ln(v) in fp32 like the reference; where var is (nearly) constant along D the
+    # <=1-ulp rounding of logf is COHERENT over the D terms (D * 0.5 ulp(9.2) = 5e-4 at D=1024), for
+    # the reference's logf just as for ours.  Bar: 2e-3 absolute, i.e. ~3e-7 relative.
+    TOL = 2e-3
+    err64 = (scores.cpu().double() - ref64).abs().max().item()
+    ref_err = (ref32.double() - ref64).abs().max().item()
+    assert err64 <= TOL, err64
+    assert (scores.cpu() - ref32).abs().max().item() <= ref_err + TOL
+    ll64 = O.gmm_log_likelihood(x.double(), st.mu.double(), O.gmm_get_var(_as64(st)))
+    assert (ll.cpu().double() - ll64).abs().max().item() <= TOL
+    assert (joint.cpu().double() - O.gmm_joint(_as64(st), x.double())).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize('K,M,D,B', [(40, 8, 1024, 1), (15, 4, 512, 5), (9, 16, 768, 64)])
+def test_gmm_fit_matches_oracle(ua, K, M, D, B):
+    text, st, g = _stream_state(K, M, D, 10, 2)
+    x = torch.nn.functional.normalize(text[torch.randint(0, K, (B,), generator=g)] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+    gam = torch.softmax(100 * x @ text.T, 1)
+    mu, var, pi, c, cc = dev(st.mu), dev(st.var), dev(st.pi), dev(st.c), dev(st.class_counts)
+    ua.call('ua_gmm_fit', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(dev(x)), ua.ptr(dev(gam)),
+            B, K, M, D, st.epsilon, ua.stream_ptr())
+    ref = st.clone(); O.gmm_fit(ref, x, gam)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.c.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(pi.cpu().numpy(), ref.pi.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(mu.cpu().numpy(), ref.mu.numpy(), rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(var.cpu().numpy(), ref.var.numpy(), rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(cc.cpu().numpy(), ref.class_counts.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_gmm_fit_gamma_zero_is_identity_and_errors(ua):
+    text, st, g = _stream_state(6, 4, 256, 5, 3)
+    mu, var, pi, c, cc = dev(st.mu), dev(st.var), dev(st.pi), dev(st.c), dev(st.class_counts)
+    x = dev(text[:1]); z = torch.zeros(1, 6, device='cuda')
+    ua.call('ua_gmm_fit', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(x), ua.ptr(z), 1, 6, 4, 256, 1e-4, ua.stream_ptr())
+    np.testing.assert_allclose(mu.cpu().numpy(), st.mu.numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(var.cpu().numpy(), st.var.numpy(), rtol=1e-6, atol=1e-12)
+    assert torch.equal(c.cpu(), st.c)
+    # envelope / argument errors come back as codes, not crashes
+    with pytest.raises(RuntimeError, match='envelope'):
+        ua.call('ua_gmm_fit', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(x), ua.ptr(z), 1, 6, 4, 100, 1e-4, ua.stream_ptr())
+    with pytest.raises(RuntimeError, match='invalid'):
+        ua.call('ua_gmm_fit', None, ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(x), ua.ptr(z), 1, 6, 4, 256, 1e-4, ua.stream_ptr())
+
+
+@pytest.mark.parametrize('name', ['modelnet40', 'scanobjectnn', 'shapenet55'])
+def test_fused_step_stream_vs_golden_and_oracle(ua, golden_dir, name):
+    """predict+fit+fit in one pass, fed with the golden feature stream, WITHOUT residual learning
+    (residual learning is covered in test_gpu_harness.py): compared with the oracle stepping the
+    same stream, and the i==0 step with the reference's golden outputs."""
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    text = _t(g['text']); K, D = text.shape; M = int(g['M'])
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    mdl = DOTA_mix(cfg, D, K, text.T, num_modes=M)
+    s = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False))
+    s64 = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False), dtype=torch.float64)
+    noise_dz, noise_fin = 2e-3, 1e-3          # floors: one coherent-logf rounding / the north-star bar
+    textd = dev(text)
+    fh = torch.empty(1, D, device='cuda'); fa = torch.empty(1, D, device='cuda')
+    z = torch.empty(1, K, device='cuda'); prob = torch.empty(1, K, device='cuda'); ent = torch.empty(1, device='cuda')
+    pred = torch.empty(1, dtype=torch.int32, device='cuda'); final = torch.empty(1, K, device='cuda')
+    for i in range(g['feat'].shape[0]):
+        f, f2 = _t(g['feat'][i:i + 1]), _t(g['feat_aug'][i:i + 1])
+        ua.call('ua_clip_logits', ua.ptr(dev(f)), ua.ptr(textd), K, D, 100.0, 1, ua.ptr(fh), ua.ptr(z), ua.ptr(prob), ua.ptr(ent), ua.ptr(pred, torch.int32), ua.stream_ptr())
+        ua.call('ua_clip_logits', ua.ptr(dev(f2)), ua.ptr(textd), K, D, 100.0, 2, ua.ptr(fa), None, None, None, None, ua.stream_ptr())
+        dz = mdl.step_fused(fh, fh, fa, prob)
+        ua.call('ua_fuse_logits', ua.ptr(z), ua.ptr(dz), ua.ptr(mdl.c), K, M, 0.02, 0.1, 1, None, ua.ptr(final), None, None, ua.stream_ptr())
+        rz, rdz, rfinal, rpred = s.step(f, f2)
+        tz, tdz, tfinal, tpred = s64.step(f.double(), f2.double())
+        # The streaming update is ill-conditioned in fp32 (expanded-form variance, softmax over
+        # log-likelihoods of magnitude 3e3): the reference arithmetic itself drifts from the fp64
+        # truth (measured 0.36 on raw scores / 1e-2 on final logits after 350 samples).  The HIP
+        # path must stay as close to the truth as the fp32 reference does (factor 3), never
+        # looser than the floors above, and predictions must be identical.
+        noise_dz = max(noise_dz, (rdz.double() - tdz).abs().max().item())
+        noise_fin = max(noise_fin, (rfinal.double() - tfinal).abs().max().item())
+        np.testing.assert_allclose(z.cpu().numpy(), rz.numpy(), rtol=0, atol=2e-4)
+        assert (dz.cpu().double() - tdz).abs().max().item() <= 3 * noise_dz, i
+        assert (final.cpu().double() - tfinal).abs().max().item() <= 3 * noise_fin, i
+        assert int(pred.item()) == rpred
+        assert int(final.argmax()) == int(rfinal.argmax()) == int(tfinal.argmax())
+        if i == 0:      # no residual learning has happened yet in the golden stream either
+            np.testing.assert_allclose(final.cpu().numpy()[0], g['final'][0], rtol=0, atol=1e-3)
+            np.testing.assert_allclose(dz.cpu().numpy()[0], g['dota_raw'][0], rtol=0, atol=4e-3)
+            np.testing.assert_allclose(mdl.c.cpu().numpy(), g['snap0_c'], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(mdl.c.cpu().numpy(), s.st.c.numpy(), rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(mdl.mu.cpu().numpy(), s.st.mu.numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_dota_mix_api_batched_vs_golden(ua, golden_dir):
+    """DOTA_mix.predict/.fit with B>1 against the reference outputs (g2b fixture)."""
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    g = _load(golden_dir, 'g2b_batched_fit.npz')
+    text = _t(g['text']); K, D = text.shape
+    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.T, num_modes=int(g['M']))
+    for i in range(6):
+        z = mdl.predict(_t(g[f'x{i}']).half())
+        np.testing.assert_allclose(z.cpu().numpy(), g[f'z{i}'], rtol=0, atol=4e-3)
+        mdl.fit(_t(g[f'x{i}']), _t(g[f'g{i}']))
+        mdl.update()
+    np.testing.assert_allclose(mdl.c.cpu().numpy(), g['end_c'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(mdl.pi.cpu().numpy(), g['end_pi'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(mdl.mu.cpu().numpy(), g['end_mu'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(mdl.var.cpu().numpy(), g['end_var'], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(mdl.class_counts.cpu().numpy(), g['end_class_counts'], rtol=1e-5, atol=1e-6)
+    assert mdl.t == int(g['end_t'])
+
+
+def test_fuse_logits_known_answers(ua, golden_dir):
+    g = _load(golden_dir, 'g4_fusion.npz')
+    for i in range(int(g['n'])):
+        clip, dota, c = dev(_t(g[f'clip{i}'])), dev(_t(g[f'dota{i}'])), dev(_t(g[f'c{i}']))
+        K, M = c.shape
+        out = torch.empty(1, K, device='cuda'); rank = torch.empty(1, dtype=torch.int32, device='cuda'); pred = torch.empty(1, dtype=torch.int32, device='cuda')
+        tgt = torch.tensor([int(np.argsort(-g[f'final{i}'][0])[2])], dtype=torch.int32, device='cuda')
+        ua.call('ua_fuse_logits', ua.ptr(clip), ua.ptr(dota), ua.ptr(c), K, M, 0.02, 0.1, 1, ua.ptr(tgt, torch.int32),
+                ua.ptr(out), ua.ptr(rank, torch.int32), ua.ptr(pred, torch.int32), ua.stream_ptr())
+        np.testing.assert_allclose(out.cpu().numpy(), g[f'final{i}'], rtol=2e-6, atol=2e-5)
+        assert int(pred.item()) == int(np.argmax(g[f'final{i}']))
+        assert int(rank.item()) == 2
+
+
+def test_clip_logits_matches_oracle(ua):
+    g = torch.Generator().manual_seed(5)
+    for K, D in ((40, 1024), (1156, 1024), (15, 512), (4096, 1024)):
+        text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+        feat = (text[3:4] + 0.05 * torch.randn(1, D, generator=g)) * 3.7
+        fh = torch.empty(1, D, device='cuda'); z = torch.empty(1, K, device='cuda'); p = torch.empty(1, K, device='cuda')
+        ent = torch.empty(1, device='cuda'); pred = torch.empty(1, dtype=torch.int32, device='cuda')
+        ua.call('ua_clip_logits', ua.ptr(dev(feat)), ua.ptr(dev(text)), K, D, 100.0, 1, ua.ptr(fh), ua.ptr(z), ua.ptr(p), ua.ptr(ent), ua.ptr(pred, torch.int32), ua.stream_ptr())
+        rf, rz, rent, rp, rpred = O.clip_logits(feat, text)
+        np.testing.assert_allclose(fh.cpu().numpy(), rf.numpy(), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(z.cpu().numpy(), rz.numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(p.cpu().numpy(), rp.numpy(), rtol=1e-4, atol=1e-7)
+        assert abs(ent.item() - rent.item()) < 1e-5
+        assert int(pred.item()) == int(rpred)
+
+
+# ------------------------------------------------------------------ residual learning kernels
+def test_alignment_kernels_vs_golden(ua, golden_dir):
+    g = _load(golden_dir, 'g3_alignment_scanobjectnn.npz')
+    K, M = g['pi'].shape; D = g['mu'].shape[2]
+    mu, var, pi = dev(_t(g['mu'])), dev(_t(g['var'])), dev(_t(g['pi']))
+    text0, res = dev(_t(g['text'])), dev(_t(g['res']))
+    e = torch.empty(K, D, device='cuda'); nrm = torch.empty(K, device='cuda')
+    ua.call('ua_text_normalize', ua.ptr(text0), ua.ptr(res), K, D, 0.0, ua.ptr(e), ua.ptr(nrm), ua.stream_ptr())
+    L = torch.empty(K, K, device='cuda'); joint = torch.empty(K, K, M, device='cuda')
+    ua.call('ua_gmm_loglik', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(e), K, K, M, D, float(g['eps']), ua.ptr(L), ua.ptr(joint), None, ua.stream_ptr())
+    np.testing.assert_allclose(L.cpu().numpy(), g['L'], rtol=0, atol=3e-3)
+    loss = torch.empty(1, device='cuda'); gll = torch.empty(K, K, M, device='cuda')
+    ua.call('ua_align_loss', ua.ptr(L), ua.ptr(joint), K, M, ua.ptr(loss), ua.ptr(gll), ua.stream_ptr())
+    assert abs(loss.item() - float(g['loss'])) < 2e-6
+    ge = torch.empty(K, D, device='cuda')
+    ua.call('ua_gmm_loglik_bwd', ua.ptr(mu), ua.ptr(var), ua.ptr(e), ua.ptr(gll), K, K, M, D, float(g['eps']), ua.ptr(ge), ua.stream_ptr())
+    # chain through e = t/|t| on the host (fp64) and compare with the reference's autograd gradient
+    ged, ed, n = ge.cpu().double(), e.cpu().double(), nrm.cpu().double()
+    gt = (ged - ed * (ged * ed).sum(1, keepdim=True)) / n[:, None]
+    ref = _t(g['grad_res']).double()
+    assert (gt - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # sign agreement where the gradient is not at round-off level (what Adam's first step sees)
+    big = ref.abs() > 1e-3 * ref.abs().max()
+    assert torch.equal(torch.sign(gt[big]), torch.sign(ref[big]))
+
+
+def test_residual_adam_matches_oracle(ua):
+    g = torch.Generator().manual_seed(9)
+    K, D = 12, 512
+    text0 = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    res = 0.01 * torch.randn(K, D, generator=g)
+    a = O.AdamState(torch.zeros(K, D), torch.zeros(K, D))
+    d_res, d_m, d_v = dev(res), dev(a.m), dev(a.v)
+    d_e = torch.empty(K, D, device='cuda'); d_n = torch.empty(K, device='cuda')
+    ua.call('ua_text_normalize', ua.ptr(dev(text0)), ua.ptr(d_res), K, D, 0.0, ua.ptr(d_e), ua.ptr(d_n), ua.stream_ptr())
+    for step in range(1, 6):
+        ge = torch.randn(K, D, generator=g) * 10 ** float(torch.randint(-3, 3, (1,), generator=g))
+        r = res.clone().requires_grad_(True)
+        t = text0 + r
+        e = t / t.norm(dim=1, keepdim=True)
+        (gr,) = torch.autograd.grad((e * ge).sum(), r)
+        O.adam_step(res, gr, a)
+        ua.call('ua_residual_adam', ua.ptr(dev(text0)), ua.ptr(d_res), ua.ptr(d_m), ua.ptr(d_v), ua.ptr(dev(ge)), ua.ptr(d_e), ua.ptr(d_n),
+                K, D, step, 1e-3, 0.9, 0.999, 1e-8, ua.stream_ptr())
+        np.testing.assert_allclose(d_res.cpu().numpy(), res.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(d_m.cpu().numpy(), a.m.numpy(), rtol=1e-4, atol=1e-6 * float(gr.abs().max()) + 1e-12)
+    t = text0 + res
+    np.testing.assert_allclose(d_e.cpu().numpy(), (t / t.norm(dim=1, keepdim=True)).numpy(), rtol=0, atol=3e-6)
+
+
+def test_loglik_autograd_function(ua):
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    text, st, g = _stream_state(10, 4, 256, 8, 4)
+    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, 256, 10, text.T, num_modes=4)
+    mdl.mu.copy_(st.mu); mdl.var.copy_(st.var); mdl.pi.copy_(st.pi); mdl.c.copy_(st.c)
+    x = torch.nn.functional.normalize(torch.randn(5, 256, generator=g), dim=1)
+    xd = dev(x).requires_grad_(True)
+    ll = mdl._log_likelihood(xd, mdl.mu, mdl._get_var())
+    w = torch.randn(5, 10, 4, generator=g)
+    (ll * dev(w)).sum().backward()
+    xr = x.double().requires_grad_(True)
+    llr = O.gmm_log_likelihood(xr, st.mu.double(), O.gmm_get_var(_as64(st)))
+    (llr * w.double()).sum().backward()
+    assert (ll.detach().cpu().double() - llr.detach()).abs().max().item() < 6e-4
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= 1e-5 * xr.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------ grouping kernels
+def test_fps_pure_torch_flavour_golden(ua, golden_dir):
+    g = _load(golden_dir, 'g7_fps.npz')
+    xyz = dev(_t(g['xyz']))
+    idx = torch.empty(1, 64, dtype=torch.int32, device='cuda'); cen = torch.empty(1, 64, 3, device='cuda')
+    ua.call('ua_fps', ua.ptr(xyz), 1, 1024, 64, int(g['start']), -1.0, ua.ptr(idx, torch.int32), ua.ptr(cen), ua.stream_ptr())
+    assert np.array_equal(cen.cpu().numpy(), g['centers'])
+
+
+@pytest.mark.parametrize('N,G,skip', [(1024, 512, 1e-3), (1024, 128, -1.0), (2048, 64, 1e-3), (300, 50, -1.0)])
+def test_fps_matches_oracle(ua, N, G, skip):
+    g = torch.Generator().manual_seed(N + G)
+    xyz = torch.randn(3, N, 3, generator=g); xyz = xyz / xyz.norm(dim=-1).max()
+    xyz[0, 5] = 0.0; xyz[1, :4] *= 1e-3                       # points inside the pointnet2 skip radius
+    idx = torch.empty(3, G, dtype=torch.int32, device='cuda'); cen = torch.empty(3, G, 3, device='cuda')
+    ua.call('ua_fps', ua.ptr(dev(xyz)), 3, N, G, 0, skip, ua.ptr(idx, torch.int32), ua.ptr(cen), ua.stream_ptr())
+    ref = O.fps(xyz, G, start=0, skip_origin_eps=skip)
+    assert torch.equal(idx.cpu().long(), ref)
+    assert torch.equal(cen.cpu(), xyz[torch.arange(3)[:, None], ref])
+
+
+def test_knn_group_golden(ua, golden_dir):
+    g = _load(golden_dir, 'g5_group.npz')
+    xyz, rgb, cidx = _t(g['xyz']), _t(g['rgb']), _t(g['center_idx'])
+    B, N, _ = xyz.shape; G = cidx.shape[1]; S = 32
+    centers = xyz[torch.arange(B)[:, None], cidx]
+    feat = torch.full((B * G * S, 8), 7.0, device='cuda'); idx = torch.empty(B, G, S, dtype=torch.int32, device='cuda')
+    ua.call('ua_knn_group', ua.ptr(dev(xyz)), ua.ptr(dev(rgb)), ua.ptr(dev(centers)), B, N, G, S, ua.ptr(feat), 8, ua.ptr(idx, torch.int32), ua.stream_ptr())
+    got = idx.cpu().long().numpy()
+    want = g['idx_sorted']
+    # the fixture contains duplicated points (exact distance ties; torch.topk picks among them
+    # arbitrarily, the kernel takes the lowest indices) and near-ties can differ by rounding (the
+    # reference's CPU sgemm accumulation order is unspecified): demand >= 99 % identical neighbour
+    # sets and that every differing pick is a true (near-)tie.
+    same = (got == want).all(-1)
+    assert same.mean() >= 0.99, same.mean()
+    sq = O.square_distance(centers, xyz)
+    for b, gi in zip(*np.nonzero(~same)):
+        a, w = set(got[b, gi]), set(want[b, gi])
+        da = max(sq[b, gi, list(a - w)]); dw = max(sq[b, gi, list(w - a)])
+        assert abs(float(da) - float(dw)) < 1e-6
+    ocen, ofeat, oidx = O.group_points(xyz, rgb, cidx, S)
+    f = feat.cpu().reshape(B, G, S, 8)
+    ok = torch.from_numpy(same)
+    assert torch.equal(f[ok][..., :6], ofeat[ok])
+    assert torch.equal(f[..., 6:], torch.zeros(B, G, S, 2))
+
+
+# ------------------------------------------------------------------ dense kernels
+def _gemm(ua, A, W, M, N, K, ldc=None, C_out=True, **ep):
+    from uni_adapter_amd.lib import GemmEpilogue
+    e = GemmEpilogue()
+    keep = []
+    for k, v in ep.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v); setattr(e, k, v.data_ptr())
+        else:
+            setattr(e, k, v)
+    n_out = N // 2 if ep.get('act', 0) == 3 else N
+    ldc = ldc or n_out
+    Cd = torch.zeros(M, ldc, device='cuda') if C_out else None
+    ua.call('ua_gemm', ua.ptr(A), A.stride(0), ua.ptr(W), W.stride(0), ua.ptr(Cd) if C_out else None, ldc, M, N, K, C.byref(e), ua.stream_ptr())
+    return Cd
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (513, 1024, 1024), (1026, 3072, 1024), (77, 200, 36), (4104, 1024, 2752), (2048, 128, 8), (64, 64, 4)])
+def test_gemm_plain_and_bias(ua, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    Cd = _gemm(ua, dev(A), dev(W), M, N, K, bias=dev(b))
+    ref = A.double() @ W.double().T + b.double()
+    err = (Cd.cpu().double() - ref).abs().max().item()
+    ref32 = (A @ W.T + b)
+    assert err <= max(2e-5, 2.0 * (ref32.double() - ref).abs().max().item()), err
+
+
+def test_gemm_epilogues(ua):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 256, 192, 64
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / 8; b = torch.randn(N, generator=g)
+    sc = 1 + 0.1 * torch.randn(N, generator=g); sh = torch.randn(N, generator=g)
+    rga = torch.randn(M // 64, N, generator=g); res = torch.randn(M, N, generator=g)
+    base = A.double() @ W.double().T + b.double()
+    # BN-affine + ReLU + rowgroup add + max-pool (mini-PointNet convs)
+    pool = torch.empty(M // 64, N, device='cuda')
+    Cd = _gemm(ua, dev(A), dev(W), M, N, K, bias=dev(b), scale=dev(sc), shift=dev(sh), rowgroup_add=dev(rga), ldg=N, group_rows=64,
+               act=1, pool_out=pool, ldp=N, pool_rows=64)
+    ref = torch.relu((base + rga.double().repeat_interleave(64, 0)) * sc.double() + sh.double())
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+    assert (pool.cpu().double() - ref.reshape(M // 64, 64, N).max(1)[0]).abs().max().item() < 5e-5
+    # pool only, no C
+    pool2 = torch.empty(M // 64, N, device='cuda')
+    _gemm(ua, dev(A), dev(W), M, N, K, C_out=False, bias=dev(b), pool_out=pool2, ldp=N, pool_rows=64)
+    assert (pool2.cpu().double() - base.reshape(M // 64, 64, N).max(1)[0]).abs().max().item() < 5e-5
+    # GELU + residual
+    Cd = _gemm(ua, dev(A), dev(W), M, N, K, bias=dev(b), act=2, residual=dev(res), ldr=N)
+    ref = torch.nn.functional.gelu(base) + res.double()
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+    # SwiGLU: columns in 32-blocks [gate | up]
+    Wg, Wu = W[:96], W[96:]; bg, bu = b[:96], b[96:]
+    Wc = torch.stack([Wg.reshape(3, 32, K), Wu.reshape(3, 32, K)], 1).reshape(N, K)
+    bc = torch.stack([bg.reshape(3, 32), bu.reshape(3, 32)], 1).reshape(N)
+    Cd = _gemm(ua, dev(A), dev(Wc), M, N, K, bias=dev(bc), act=3)
+    ref = torch.nn.functional.silu(A.double() @ Wg.double().T + bg.double()) * (A.double() @ Wu.double().T + bu.double())
+    assert Cd.shape == (M, 96)
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+
+
+def test_layernorm(ua):
+    g = torch.Generator().manual_seed(4)
+    for rows, cols, pad in ((513, 1024, 1024), (100, 2730, 2752), (7, 384, 384)):
+        ld = pad
+        x = torch.zeros(rows, ld); x[:, :cols] = torch.randn(rows, cols, generator=g) * 3 + 1.5
+        w = torch.randn(cols, generator=g); b = torch.randn(cols, generator=g)
+        y = torch.full((rows, ld), 9.0, device='cuda')
+        ua.call('ua_layernorm', ua.ptr(dev(x)), ld, ua.ptr(dev(w)), ua.ptr(dev(b)), 1e-6, ua.ptr(y), ld, rows, cols, pad, ua.stream_ptr())
+        ref = torch.nn.functional.layer_norm(x[:, :cols].double(), (cols,), w.double(), b.double(), 1e-6)
+        assert (y.cpu()[:, :cols].double() - ref).abs().max().item() < 2e-5
+        assert torch.equal(y.cpu()[:, cols:], torch.zeros(rows, pad - cols))
+
+
+@pytest.mark.parametrize('Bc,G,H', [(2, 512, 16), (1, 128, 2), (3, 256, 4)])
+def test_attention(ua, Bc, G, H):
+    g = torch.Generator().manual_seed(Bc * G + H)
+    hd, C = 64, H * 64
+    rows = Bc * G + Bc
+    qkv = torch.randn(rows, 3 * C, generator=g) * 1.5
+    out = torch.zeros(rows, C, device='cuda')
+    ua.call('ua_attention', ua.ptr(dev(qkv)), 3 * C, ua.ptr(out), C, Bc, G, H, hd, ua.stream_ptr())
+    o = out.cpu().double()
+    for b in range(Bc):
+        r = torch.cat([torch.arange(b * G, (b + 1) * G), torch.tensor([Bc * G + b])])
+        x = qkv[r].double()
+        q, k, v = [t.reshape(G + 1, H, hd).transpose(0, 1) for t in x.split(C, -1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(0, 1).reshape(G + 1, C)
+        assert (o[r] - ref).abs().max().item() < 2e-5

@@ -1,0 +1,288 @@
+"""Test-time adaptation harness on MI355X: drop-in for the reference `Uni_Adapter.py`
+(`test_zeroshot_3d_core`, `get_logits_wrapper`, `softmax_entropy`, `compute_text_alignment_loss`)
+for the `--use-mode-dota` path (the only one reachable from the reference CLI).
+
+How the loop is organised on the device (same arithmetic per sample as Uni_Adapter.py:368-579):
+  * the encoder is stateless, so the clouds of a CHUNK of samples (original + augmented) are
+    encoded together - big, tile-aligned GEMMs instead of T=513-row ones;
+  * the cache step is sequential in the stream (sample i sees the state left by samples < i), so it
+    is replayed per sample, in order, from the chunk's features: clip logits -> fused
+    predict+fit+fit -> residual learning (10 Adam steps) -> fusion.  Nothing in that replay touches
+    the host: predictions, ranks and logits stay in HBM until the chunk (or the stream) ends;
+  * with torch.distributed initialised (one process per GPU, RCCL), rank r encodes samples
+    i = r (mod W) of every chunk, features are exchanged with ONE all_gather per chunk and every
+    rank replays the identical cache sequence on its replica of the state ("exact mode": results
+    are independent of the GPU count).
+"""
+import logging
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import lib
+from .dota_mixture import DOTA_mix
+
+LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
+NOISE_STD = 0.05             # Uni_Adapter.py:420
+RES_STEPS = 10               # Uni_Adapter.py:467
+RES_LR = 1e-3                # Uni_Adapter.py:350-351 (start == end)
+
+
+# ----------------------------------------------------------------------------- small mirrors
+def softmax_entropy(x, enable_softmax=True, temperature=1.0):
+    """Uni_Adapter.py:21-26 (host-side helper kept for API compatibility; the hot loop uses the
+    fused kernels)."""
+    probs = torch.softmax(x / temperature, dim=1) if enable_softmax else x
+    return -(probs * torch.log(probs + 1e-10)).sum(dim=1)
+
+
+def get_logits_wrapper(args, model, feature, clip_weights):
+    """Uni_Adapter.py:53-75 for vlm3d == 'uni3d', batch 1.  `clip_weights` is (D,K) as in the
+    reference.  Returns (pc_features, logits, loss, prob_map, pred:int)."""
+    if getattr(args, 'vlm3d', 'uni3d') != 'uni3d':
+        raise NotImplementedError('only --vlm3d uni3d is wired end-to-end (as in the reference, SURVEY section 0)')
+    feat = model.encode_pc(feature)
+    if feat.shape[0] != 1:
+        raise ValueError('batch size must be 1 (reference defect 6)')
+    text = clip_weights.t().contiguous()
+    K, D = text.shape
+    dev = feat.device
+    fh = torch.empty(1, D, device=dev); z = torch.empty(1, K, device=dev); p = torch.empty(1, K, device=dev)
+    ent = torch.empty(1, device=dev); pred = torch.empty(1, dtype=torch.int32, device=dev)
+    lib.call('ua_clip_logits', lib.ptr(feat.contiguous()), lib.ptr(text), K, D, LOGIT_SCALE, 1, lib.ptr(fh), lib.ptr(z),
+             lib.ptr(p), lib.ptr(ent), lib.ptr(pred, torch.int32), lib.stream_ptr())
+    return fh, z, ent, p, int(pred.item())
+
+
+class _AlignLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, mdl):
+        K, M, D = mdl.num_classes, mdl.num_modes, mdl.input_shape
+        e = e.contiguous()
+        L, joint = mdl.joint(e)
+        loss = torch.empty(1, device=e.device); gll = torch.empty(K, K, M, device=e.device)
+        lib.call('ua_align_loss', lib.ptr(L), lib.ptr(joint), K, M, lib.ptr(loss), lib.ptr(gll), lib.stream_ptr())
+        ge = torch.empty(K, D, device=e.device)
+        lib.call('ua_gmm_loglik_bwd', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(e), lib.ptr(gll), K, K, M, D, mdl.epsilon,
+                 lib.ptr(ge), lib.stream_ptr())
+        ctx.save_for_backward(ge)
+        ctx.mark_non_differentiable(L)
+        return loss.reshape(()), L
+
+    @staticmethod
+    def backward(ctx, g_loss, g_L):
+        (ge,) = ctx.saved_tensors
+        return ge * g_loss, None
+
+
+def compute_text_alignment_loss(class_embeddings, mode_dota_model):
+    """Uni_Adapter.py:191-270: returns (loss, likelihood_matrix); loss is differentiable w.r.t.
+    class_embeddings (K,D)."""
+    if not class_embeddings.requires_grad:
+        raise RuntimeError("class_embeddings must require gradients for optimization")
+    return _AlignLoss.apply(class_embeddings.float(), mode_dota_model)
+
+
+# ----------------------------------------------------------------------------- engine
+class TextResiduals:
+    """text_residuals + torch.optim.Adam state + the current normalised text matrix
+    (Uni_Adapter.py:346-352, 388-393), all resident on the device."""
+
+    def __init__(self, text0):
+        self.text0 = text0.contiguous()
+        K, D = text0.shape
+        dev = text0.device
+        self.res = torch.zeros(K, D, device=dev)
+        self.m = torch.zeros(K, D, device=dev)
+        self.v = torch.zeros(K, D, device=dev)
+        self.e = torch.empty(K, D, device=dev)
+        self.norm = torch.empty(K, device=dev)
+        self.step = 0
+        lib.call('ua_text_normalize', lib.ptr(self.text0), lib.ptr(self.res), K, D, 0.0, lib.ptr(self.e), lib.ptr(self.norm),
+                 lib.stream_ptr())
+
+
+class TtaEngine:
+    """Per-corruption state + the chunked loop body.  One instance per call of
+    test_zeroshot_3d_core (the reference rebuilds all state per corruption, Uni_Adapter.py:336-352)."""
+
+    def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
+                 log_alignment_every=0, dist_group=None):
+        self.model = model
+        self.dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.text = text_features.detach().to(self.dev, torch.float32).contiguous()          # (K,D)
+        self.K, self.D = self.text.shape
+        self.M = int(num_modes)
+        self.cfg = dict(dota_cfg)
+        self.res_learning = bool(res_learning)
+        self.chunk = int(chunk)
+        self.log_every = int(log_alignment_every)
+        self.mode_dota_model = DOTA_mix(self.cfg, self.D, self.K, self.text.t(), num_modes=self.M, device=self.dev)
+        self.mode_dota_model.eval()
+        self.residuals = TextResiduals(self.text) if self.res_learning else None
+        self.i = 0                                                                           # samples seen
+        self.world, self.rank, self.group = 1, 0, dist_group
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(dist_group)
+            self.rank = torch.distributed.get_rank(dist_group)
+        K, D, M, dev = self.K, self.D, self.M, self.dev
+        e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
+        self.fh, self.fa = e(1, D), e(1, D)
+        self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
+        self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
+        self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
+        self.count = 0
+        self.last_loss = None
+
+    # -- encoder part: this rank's share of the chunk -------------------------------------
+    def encode_chunk(self, pc, rgb, noise):
+        """pc, rgb (n,N,3); noise (n,N,3) = the randn draw of Uni_Adapter.py:421.  Returns
+        features (n,2,D): [:,0] original, [:,1] augmented cloud."""
+        n = pc.shape[0]
+        mine = torch.arange(self.rank, n, self.world)
+        D = self.D
+        feats = torch.zeros(n, 2, D, device=self.dev)
+        if len(mine):
+            p, c, z = pc[mine], rgb[mine], noise[mine]
+            clouds = torch.stack([torch.cat((p, c), -1), torch.cat((p + NOISE_STD * z, c), -1)], 1)      # :385, :421-422
+            f = self.model.encode_pc(clouds.view(-1, clouds.shape[2], 6))
+            feats[mine] = f.view(len(mine), 2, D)
+        if self.world > 1:
+            # one exchange per chunk: every rank contributes the rows it encoded (zeros elsewhere),
+            # RCCL all_gather over xGMI, then select each sample's row from its owner.
+            allf = [torch.empty_like(feats) for _ in range(self.world)]
+            torch.distributed.all_gather(allf, feats, group=self.group)
+            owner = torch.arange(n, device=self.dev) % self.world
+            feats = torch.stack(allf, 0)[owner, torch.arange(n, device=self.dev)]
+        return feats
+
+    # -- sequential cache step of ONE sample ----------------------------------------------
+    def cache_step(self, feat, feat_aug, target, out_final, out_rank, out_pred):
+        """feat, feat_aug: (1,D) encoder outputs; target: int32 (1,) device tensor or None.
+        Writes final logits (1,K), rank (1,), pred (1,) into the given device views."""
+        K, M, D = self.K, self.M, self.D
+        st = lib.stream_ptr()
+        mdl = self.mode_dota_model
+        text = self.residuals.e if self.res_learning else self.text                         # :388-401
+        lib.call('ua_clip_logits', lib.ptr(feat), lib.ptr(text), K, D, LOGIT_SCALE, 1, lib.ptr(self.fh), lib.ptr(self.z),
+                 lib.ptr(self.prob), lib.ptr(self.ent), None, st)                            # :406
+        lib.call('ua_clip_logits', lib.ptr(feat_aug), lib.ptr(text), K, D, LOGIT_SCALE, 2, lib.ptr(self.fa), None, None, None,
+                 None, st)                                                                   # :424,:429
+        mdl.step_fused(self.fh, self.fh, self.fa, self.prob, scores=self.dz)                 # :416,:417,:430
+        if self.i > 0 and self.res_learning:                                                 # :444-476
+            r = self.residuals
+            for _ in range(RES_STEPS):
+                self._align_eval(r, with_grad=True)
+                r.step += 1
+                lib.call('ua_residual_adam', lib.ptr(r.text0), lib.ptr(r.res), lib.ptr(r.m), lib.ptr(r.v), lib.ptr(self.ge),
+                         lib.ptr(r.e), lib.ptr(r.norm), K, D, r.step, RES_LR, 0.9, 0.999, 1e-8, st)
+            if self.log_every and self.i % self.log_every == 0:                              # :480-485
+                self._align_eval(r, with_grad=False)
+                self.last_loss = self.loss.clone()
+        lib.call('ua_fuse_logits', lib.ptr(self.z), lib.ptr(self.dz), lib.ptr(mdl.c), K, M, float(self.cfg['rho']),
+                 float(self.cfg['eta']), 1, lib.ptr(target, torch.int32) if target is not None else None,
+                 lib.ptr(out_final), lib.ptr(out_rank, torch.int32) if target is not None else None,
+                 lib.ptr(out_pred, torch.int32), st)                                         # :491-521
+        self.i += 1
+
+    def _align_eval(self, r, with_grad):
+        K, M, D = self.K, self.M, self.D
+        mdl = self.mode_dota_model
+        st = lib.stream_ptr()
+        lib.call('ua_gmm_loglik', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(mdl.pi), lib.ptr(r.e), K, K, M, D, mdl.epsilon,
+                 lib.ptr(self.L), lib.ptr(self.joint), None, st)
+        lib.call('ua_align_loss', lib.ptr(self.L), lib.ptr(self.joint), K, M, lib.ptr(self.loss),
+                 lib.ptr(self.gll) if with_grad else None, st)
+        if with_grad:
+            lib.call('ua_gmm_loglik_bwd', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(r.e), lib.ptr(self.gll), K, K, M, D,
+                     mdl.epsilon, lib.ptr(self.ge), st)
+
+    # -- one chunk ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def process_chunk(self, pc, rgb, target=None, noise=None, generator=None):
+        """pc, rgb: (n,N,3); target: (n,) or None; noise: (n,N,3) or None (drawn on device).
+        Returns (final_logits (n,K), ranks (n,) int32, preds (n,) int32) - device tensors."""
+        pc = pc.to(self.dev, torch.float32, non_blocking=True)
+        rgb = rgb.to(self.dev, torch.float32, non_blocking=True)
+        n = pc.shape[0]
+        if noise is None:
+            noise = torch.randn(pc.shape, device=self.dev, generator=generator)              # :421
+        else:
+            noise = noise.to(self.dev, torch.float32)
+        feats = self.encode_chunk(pc, rgb, noise)
+        final = torch.empty(n, self.K, device=self.dev)
+        ranks = torch.full((n,), -1, device=self.dev, dtype=torch.int32)
+        preds = torch.empty(n, device=self.dev, dtype=torch.int32)
+        tgt = target.to(self.dev, torch.int32) if target is not None else None
+        for j in range(n):
+            self.cache_step(feats[j, 0:1], feats[j, 1:2], tgt[j:j + 1] if tgt is not None else None,
+                            final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
+        if tgt is not None:                                                                  # utils/utils.py:154-167
+            self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
+            self.count += n
+        return final, ranks, preds
+
+    def accuracy(self):
+        """{'acc1','acc3','acc5'} in percent over everything processed so far (host sync)."""
+        c = self.correct.tolist()
+        d = max(1, self.count)
+        return {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}
+
+
+# ----------------------------------------------------------------------------- entry point
+def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model, tokenizer, args, hp):
+    """Same signature and return value as Uni_Adapter.py:272-595.  `test_loader` yields
+    (pc, target, target_name, rgb) with any batch size; samples are consumed in stream order.
+    Extra optional attributes read from `args` (never required):
+      chunk_size (16), aug_noise (callable(sample_index0, pc) -> noise, for reproducible streams)."""
+    if not getattr(args, 'use_mode_dota', True):
+        raise NotImplementedError('only the --use-mode-dota path is built (the reference CLI cannot reach the others)')
+    model.eval()
+    dota_cfg = {'epsilon': args.dota_epsilon, 'sigma': args.dota_sigma, 'eta': args.dota_eta, 'rho': args.dota_rho}
+    logging.info(f"MODE DOTA Hyperparameters: {dota_cfg}")
+    logging.info(f"num MODES for MODE DOTA: {args.mode_M}")
+    dev = torch.device(args.device if getattr(args, 'device', None) else 'cuda')
+    ptf = getattr(args, 'precomputed_text_features', None)
+    if isinstance(ptf, torch.Tensor):
+        text_features = ptf
+    elif ptf and os.path.exists(ptf):
+        logging.info(f"Loading precomputed text features from {ptf}")
+        text_features = torch.load(ptf, map_location='cpu', weights_only=True)               # :298-300
+    else:
+        raise FileNotFoundError('precomputed text features are required (the text tower is out of scope): '
+                                '--precomputed-text-features')
+    chunk = int(getattr(args, 'chunk_size', 16))
+    eng = TtaEngine(model, text_features, dota_cfg, args.mode_M, res_learning=getattr(args, 'res_learning', True),
+                    chunk=chunk, device=dev, log_alignment_every=getattr(args, 'print_freq', 0))
+    logging.info(f"Initialized MODE-DOTA model with M={args.mode_M}.")
+    noise_fn = getattr(args, 'aug_noise', None)
+    start_event, end_event = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start_event.record()
+    buf_pc, buf_rgb, buf_t = [], [], []
+    seen = 0
+
+    def flush():
+        nonlocal seen
+        if not buf_pc:
+            return
+        pc, rgb, t = torch.cat(buf_pc), torch.cat(buf_rgb), torch.cat(buf_t)
+        noise = torch.cat([noise_fn(seen + j, pc[j:j + 1]) for j in range(pc.shape[0])]) if noise_fn else None
+        eng.process_chunk(pc, rgb, t, noise)
+        seen += pc.shape[0]
+        buf_pc.clear(); buf_rgb.clear(); buf_t.clear()
+
+    for pc, target, target_name, rgb in test_loader:
+        pc, rgb, target = torch.as_tensor(pc), torch.as_tensor(rgb), torch.as_tensor(target).reshape(-1)
+        for j in range(pc.shape[0]):
+            buf_pc.append(pc[j:j + 1]); buf_rgb.append(rgb[j:j + 1]); buf_t.append(target[j:j + 1])
+            if len(buf_pc) == chunk:
+                flush()
+    flush()
+    end_event.record()
+    torch.cuda.synchronize()
+    acc = eng.accuracy()
+    logging.info(f"Final Results: Acc@1 {acc['acc1']:.3f} Acc@3 {acc['acc3']:.3f} Acc@5 {acc['acc5']:.3f}")
+    logging.info(f"Total time: {start_event.elapsed_time(end_event):.3f} ms")
+    return acc

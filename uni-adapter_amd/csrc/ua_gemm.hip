@@ -1,0 +1,213 @@
+// C = A @ W^T (+ fused epilogue) on the CDNA4 matrix cores with EXACT fp32 arithmetic
+// (v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-identical to an fmaf chain).
+//
+// Serves every Linear / Conv1d(k=1) of the Uni3D encoder: mini-PointNet convs
+// (models/point_encoder.py:133-144), encoder2trans / pos_embed / trans2embed (:175-186) and the
+// q/k/v/proj/fc1/fc2 projections of the 24 timm EvaBlocks (:217-218) - >99 % of the path's FLOPs.
+// The reference runs Uni3D in fp32 (utils/load_models.py:51-61) and the parity bar is 1e-3 on
+// 100*cos logits, so the contraction stays fp32 (bf16 MFMA would not hold it over 24 layers).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup, 4 wavefronts as 2x2, each wave a 64x64
+// sub-tile = 2x2 MFMA blocks of 32x32 (64 accumulator VGPRs).  K is consumed in 32-wide slabs
+// that are double-buffered in LDS ([128][36] floats: the +4 pad makes every ds_read_b128 of a
+// 16-lane group hit 16 distinct 16-byte bank slots).  A and W are both K-contiguous, so both
+// operands use the same fragment read: lane (i = lane&31, h = lane>>5) fetches row i, columns
+// 8c+4h..8c+4h+3 with ONE ds_read_b128 and feeds them to four consecutive MFMAs - the k index
+// inside a slab is permuted identically for A and W, which leaves the sum unchanged.
+// The next slab is fetched global->VGPR while the current one is multiplied (the f32 MFMA is
+// 64 cycles per instruction, so 64 MFMAs per slab hide the staging entirely).
+// Workgroup ids are remapped so that each XCD (blockIdx % 8) owns a contiguous band of row
+// panels: the A panel of a band is fetched from HBM once and re-used from that XCD's L2 by all
+// column tiles.
+#include "ua_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_LD = BK + 4;                       // floats per LDS row
+constexpr int TILE_F = BM * LDS_LD;                  // floats per operand tile
+
+struct GemmArgs {
+    const float* A; const float* W; float* C;
+    long long lda, ldw, ldc;
+    int M, N, K;
+    const float* bias; const float* scale; const float* shift;
+    const float* rga; long long ldg; int group_rows;
+    int act;
+    const float* residual; long long ldr;
+    float* pool; long long ldp;
+    int tiles_n, n_tiles;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float4 ld_guard(const float* base, long long ld, int row, int nrows, int k, int K) {
+    if (row < nrows && k < K) return *reinterpret_cast<const float4*>(base + (size_t)row * ld + k);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2 buffers][A tile | W tile]
+    // ---- XCD-aware tile id (bijective for any n_tiles) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = g.n_tiles >> 3, r = g.n_tiles & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging map: 4 float4 per thread per operand; f = tid + 256*i -> row f/8, k-quad f%8
+    float4 ra[4], rw[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kq = (f & 7) * 4;
+            ra[i] = ld_guard(g.A, g.lda, m0 + row, g.M, k0 + kq, g.K);
+            rw[i] = ld_guard(g.W, g.ldw, n0 + row, g.N, k0 + kq, g.K);
+        }
+    };
+    auto stash = [&](int buf) {
+        float* a = lds + buf * 2 * TILE_F;
+        float* w = a + TILE_F;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kq = (f & 7) * 4;
+            *reinterpret_cast<float4*>(a + row * LDS_LD + kq) = ra[i];
+            *reinterpret_cast<float4*>(w + row * LDS_LD + kq) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // wave-uniform activity of the four 32x32 blocks (thin edge tiles skip their MFMAs)
+    bool on_m[2], on_n[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        on_m[i] = (m0 + wm * 64 + i * 32) < g.M;
+        on_n[i] = (n0 + wn * 64 + i * 32) < g.N;
+    }
+
+    const int nk = (g.K + BK - 1) / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) fetch((t + 1) * BK);
+        const float* a = lds + buf * 2 * TILE_F + (wm * 64 + li) * LDS_LD + lh * 4;
+        const float* w = lds + buf * 2 * TILE_F + TILE_F + (wn * 64 + li) * LDS_LD + lh * 4;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            float4 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + c * 8);
+                fw[i] = *reinterpret_cast<const float4*>(w + i * 32 * LDS_LD + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (on_m[i] && on_n[j]) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fw[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fw[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fw[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fw[j].w, acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (t + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = li (within the 32x32) ----
+    const bool swiglu = g.act == 3;
+    const int n_out = swiglu ? g.N / 2 : g.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (swiglu && j == 1) break;
+        const int n_in = n0 + wn * 64 + j * 32 + li;                 // column of acc[.][j]
+        const int n_up = n_in + 32;                                  // SwiGLU partner column
+        const int n = swiglu ? (n0 + wn * 64) / 2 + li : n_in;       // output column
+        const bool n_ok = n_in < g.N && n < n_out;
+        const float bj = (g.bias && n_ok) ? g.bias[n_in] : 0.f;
+        const float bu = (swiglu && g.bias && n_ok) ? g.bias[n_up] : 0.f;
+        const float sc = (g.scale && n_ok) ? g.scale[n_in] : 1.f;
+        const float sh = (g.shift && n_ok) ? g.shift[n_in] : 0.f;
+        float pmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < g.M && n_ok) {
+                    float v = acc[i][j][e] + bj;
+                    if (g.rga) v += g.rga[(size_t)(m / g.group_rows) * g.ldg + n_in];
+                    if (g.scale) v = v * sc;
+                    if (g.shift) v = v + sh;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = gelu_erf(v);
+                    else if (swiglu) v = silu(v) * (acc[i][1][e] + bu);
+                    if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
+                    if (g.C) g.C[(size_t)m * g.ldc + n] = v;
+                    pmax = fmaxf(pmax, v);
+                }
+            }
+        }
+        if (g.pool) {                                                  // max over this wave's 64 rows
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
+            const int m_grp = (m0 + wm * 64) / 64;
+            if (lh == 0 && n_ok && (m0 + wm * 64) < g.M) g.pool[(size_t)m_grp * g.ldp + n] = pmax;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                       int32_t M, int32_t N, int32_t K, const ua_gemm_epilogue* ep, void* stream) {
+    UA_CHECK_PTR(A); UA_CHECK_PTR(W);
+    UA_CHECK_ALIGN16(A); UA_CHECK_ALIGN16(W);
+    if (M <= 0 || N <= 0 || K <= 0) return UA_EINVAL;
+    if (K % 4 || lda % 4 || ldw % 4) return UA_EALIGN;
+    if (lda < K || ldw < K) return UA_EINVAL;
+    GemmArgs g{};
+    g.A = A; g.W = W; g.C = C; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    if (ep) {
+        g.bias = ep->bias; g.scale = ep->scale; g.shift = ep->shift;
+        g.rga = ep->rowgroup_add; g.ldg = ep->ldg; g.group_rows = ep->group_rows;
+        g.act = ep->act; g.residual = ep->residual; g.ldr = ep->ldr;
+        g.pool = ep->pool_out; g.ldp = ep->ldp;
+        if (g.act < 0 || g.act > 3) return UA_EINVAL;
+        if (g.rga && g.group_rows <= 0) return UA_EINVAL;
+        if (g.pool && (ep->pool_rows != 64 || M % 64 != 0)) return UA_EUNSUPPORTED;
+        if (g.act == 3 && (N % 64 != 0 || g.rga || g.scale || g.shift)) return UA_EUNSUPPORTED;
+    }
+    if (!C && !g.pool) return UA_EINVAL;
+    const int n_out = g.act == 3 ? N / 2 : N;
+    if (C && ldc < n_out) return UA_EINVAL;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
+    const size_t lds = (size_t)4 * TILE_F * sizeof(float);           // 73,728 B
+    static bool attr_set = false;                                      // idempotent, benign race
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3(g.n_tiles), dim3(256), lds, ua::as_stream(stream), g);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}

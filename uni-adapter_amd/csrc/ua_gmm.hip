@@ -1,0 +1,348 @@
+// MODE-DOTA cache kernels for gfx950 (MI355X): per-class M-mode diagonal Gaussian mixture.
+//
+// Reference semantics: dota_mixture.py:117-267 (DOTA_mix._get_var/_log_likelihood/fit/predict).
+//
+// Layout / mapping.  State mu,var are (K,M,D) fp32 with D fastest.  One workgroup owns one class
+// k; wave m of the workgroup owns mode row (k,m) and keeps the WHOLE row of mu and var in
+// registers (D = 256*VEC floats -> VEC float4 per lane per array; lane l holds float4 #(v*64+l),
+// so every wave-instruction moves 1 KiB of contiguous HBM).  Everything the reference does per
+// sample to that row (predict, fit, fit) is then done from registers, and the row is written
+// back once: 4*K*M*D*4 bytes of HBM traffic per sample instead of the reference's 10 passes.
+// Cross-lane reductions (sum over D) are wavefront butterflies; the sum over modes (logsumexp,
+// softmax responsibilities, sum_m c) goes through a few floats of LDS per class.
+//
+// Numerics.  Per-element arithmetic is fp32 in the reference's operation order (this file is
+// compiled with -ffp-contract=off so a*b+c is not fused, matching the separate torch ops).
+// The D-long sums are accumulated in fp64 and rounded to fp32 once, which is at least as
+// accurate as torch's fp32 pairwise sums (|sum| ~ 9e3, fp32 ulp there ~ 1e-3).
+#include "ua_common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+using ua::wave_sum;
+
+constexpr int kMaxModes = 16;   // waves per workgroup
+constexpr int kMaxFitB  = 64;   // samples per fit call
+constexpr int kQChunk   = 32;   // queries per workgroup in the batched log-lik kernel
+
+template <int VEC>
+struct Row {
+    float4 mu[VEC];
+    float4 var[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_row(Row<VEC>& r, const float* mu, const float* var, size_t off, int lane) {
+    const float4* pm = reinterpret_cast<const float4*>(mu + off);
+    const float4* pv = reinterpret_cast<const float4*>(var + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { r.mu[v] = pm[v * 64 + lane]; r.var[v] = pv[v * 64 + lane]; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_row(const Row<VEC>& r, float* mu, float* var, size_t off, int lane) {
+    float4* pm = reinterpret_cast<float4*>(mu + off);
+    float4* pv = reinterpret_cast<float4*>(var + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { pm[v * 64 + lane] = r.mu[v]; pv[v * 64 + lane] = r.var[v]; }
+}
+
+__device__ __forceinline__ float reg_var(float v, float eps) { return fmaxf(v + eps, 1e-8f); }   // :117-119
+
+// sum_d ln(max(var+eps,1e-8)) over the wave's row (all lanes get the total)
+template <int VEC>
+__device__ __forceinline__ double row_logdet(const Row<VEC>& r, float eps) {
+    double acc = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        acc += (double)logf(reg_var(r.var[v].x, eps));
+        acc += (double)logf(reg_var(r.var[v].y, eps));
+        acc += (double)logf(reg_var(r.var[v].z, eps));
+        acc += (double)logf(reg_var(r.var[v].w, eps));
+    }
+    return wave_sum(acc);
+}
+
+__device__ __forceinline__ float round_fp16(float x) { return __half2float(__float2half_rn(x)); }
+
+// sum_d (x-mu)^2 / v over the wave's row
+template <int VEC, bool ROUND16>
+__device__ __forceinline__ double row_maha(const Row<VEC>& r, const float* x, float eps, int lane) {
+    const float4* px = reinterpret_cast<const float4*>(x);
+    double acc = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float4 xv = px[v * 64 + lane];
+        if (ROUND16) { xv.x = round_fp16(xv.x); xv.y = round_fp16(xv.y); xv.z = round_fp16(xv.z); xv.w = round_fp16(xv.w); }
+        float d;
+        d = xv.x - r.mu[v].x; acc += (double)((d * d) / reg_var(r.var[v].x, eps));
+        d = xv.y - r.mu[v].y; acc += (double)((d * d) / reg_var(r.var[v].y, eps));
+        d = xv.z - r.mu[v].z; acc += (double)((d * d) / reg_var(r.var[v].z, eps));
+        d = xv.w - r.mu[v].w; acc += (double)((d * d) / reg_var(r.var[v].w, eps));
+    }
+    return wave_sum(acc);
+}
+
+// torch.logsumexp over M values held in LDS
+__device__ __forceinline__ float lse_modes(const float* j, int M) {
+    float mx = j[0];
+    for (int i = 1; i < M; ++i) mx = fmaxf(mx, j[i]);
+    float s = 0.f;
+    for (int i = 0; i < M; ++i) s += expf(j[i] - mx);
+    return mx + logf(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched log-likelihood / predict: grid (K, ceil(B/kQChunk)), block M*64.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(1024)
+gmm_loglik_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ pi,
+                  const float* __restrict__ x, int B, int K, int M, float eps,
+                  float* __restrict__ scores, float* __restrict__ joint, float* __restrict__ loglik) {
+    constexpr int D = 256 * VEC;
+    __shared__ float s_j[kQChunk][kMaxModes];
+    const int k = blockIdx.x, m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = blockIdx.y * kQChunk;
+    const int nq = min(kQChunk, B - q0);
+    Row<VEC> r;
+    load_row<VEC>(r, mu, var, ((size_t)k * M + m) * D, lane);
+    const double ld = row_logdet<VEC>(r, eps);
+    const float logpi = logf(pi[k * M + m] + 1e-10f);
+    for (int qi = 0; qi < nq; ++qi) {
+        const int q = q0 + qi;
+        const double mh = row_maha<VEC, false>(r, x + (size_t)q * D, eps, lane);
+        const float ll = (float)(-0.5 * (ld + mh));
+        if (lane == 0) {
+            const float jv = logpi + ll;
+            s_j[qi][m] = jv;
+            const size_t o = ((size_t)q * K + k) * M + m;
+            if (joint) joint[o] = jv;
+            if (loglik) loglik[o] = ll;
+        }
+    }
+    if (scores) {
+        __syncthreads();
+        for (int qi = threadIdx.x; qi < nq; qi += blockDim.x)
+            scores[(size_t)(q0 + qi) * K + k] = lse_modes(s_j[qi], M);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Class-resident step kernel: optional predict, then up to two fits, one pass over the state.
+// ------------------------------------------------------------------------------------------
+struct StepArgs {
+    float* mu; float* var; float* pi; float* c; float* class_counts;
+    const float* xq; int nq; int round_q; float* scores;
+    const float* xf[2]; const float* gf[2]; int bf[2]; int nfit;
+    int K, M; float eps;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(1024) gmm_step_kernel(StepArgs a) {
+    constexpr int D = 256 * VEC;
+    __shared__ float s_j[kMaxFitB][kMaxModes];   // joint log-probabilities [sample][mode]
+    __shared__ float s_c[kMaxModes];
+    const int k = blockIdx.x, m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int M = a.M, K = a.K;
+    const float eps = a.eps;
+    const size_t off = ((size_t)k * M + m) * D;
+    Row<VEC> r;
+    load_row<VEC>(r, a.mu, a.var, off, lane);
+    float c_km = a.c[k * M + m];
+    float pi_km = a.pi[k * M + m];
+    double ld = row_logdet<VEC>(r, eps);
+
+    // ---- predict (dota_mixture.py:250-258) on the state BEFORE any fit ----
+    for (int q = 0; q < a.nq; ++q) {
+        const float* xq = a.xq + (size_t)q * D;
+        const double mh = a.round_q ? row_maha<VEC, true>(r, xq, eps, lane) : row_maha<VEC, false>(r, xq, eps, lane);
+        const float ll = (float)(-0.5 * (ld + mh));
+        __syncthreads();
+        if (lane == 0) s_j[0][m] = logf(pi_km + 1e-10f) + ll;
+        __syncthreads();
+        if (threadIdx.x == 0) a.scores[(size_t)q * K + k] = lse_modes(s_j[0], M);
+    }
+
+    // ---- fits (dota_mixture.py:162-234) ----
+    for (int f = 0; f < a.nfit; ++f) {
+        const float* X = a.xf[f];
+        const float* G = a.gf[f];
+        const int B = a.bf[f];
+        if (f > 0) ld = row_logdet<VEC>(r, eps);          // var changed
+        const float logpi = logf(pi_km + 1e-10f);
+        __syncthreads();
+        for (int b = 0; b < B; ++b) {                       // E-step :176-180
+            const double mh = row_maha<VEC, false>(r, X + (size_t)b * D, eps, lane);
+            if (lane == 0) s_j[b][m] = logpi + (float)(-0.5 * (ld + mh));
+        }
+        __syncthreads();
+        // responsibilities of this wave's mode, gamma_{b,k,m} = gamma_class[b,k] * r   :183-187
+        float sum_gamma = 0.f;
+        float4 wx[VEC], wxx[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { wx[v] = make_float4(0.f, 0.f, 0.f, 0.f); wxx[v] = wx[v]; }
+        for (int b = 0; b < B; ++b) {
+            const float lse = lse_modes(s_j[b], M);
+            const float g = G[(size_t)b * K + k] * expf(s_j[b][m] - lse);
+            sum_gamma += g;                                                            // :190
+            const float4* px = reinterpret_cast<const float4*>(X + (size_t)b * D);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {                                            // :202,:213-214
+                const float4 xv = px[v * 64 + lane];
+                wx[v].x += g * xv.x; wx[v].y += g * xv.y; wx[v].z += g * xv.z; wx[v].w += g * xv.w;
+                wxx[v].x += g * (xv.x * xv.x); wxx[v].y += g * (xv.y * xv.y);
+                wxx[v].z += g * (xv.z * xv.z); wxx[v].w += g * (xv.w * xv.w);
+            }
+        }
+        const float c_new = c_km + sum_gamma;                                          // :196
+        const float den = c_new + 1e-10f;
+#define UA_UPD(F)                                                                                     \
+        {                                                                                             \
+            const float mo = r.mu[v].F, vo = r.var[v].F, w1 = wx[v].F, w2 = wxx[v].F;                 \
+            const float mn = (c_km * mo + w1) / den;                                   /* :205-206 */ \
+            const float sq = (w2 + (-2.0f * mo) * w1) + sum_gamma * (mo * mo);         /* :215-217 */ \
+            const float vn = (c_km * vo + sq) / den;                                   /* :219-220 */ \
+            r.mu[v].F = mn; r.var[v].F = fmaxf(vn, 1e-8f);                             /* :223     */ \
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { UA_UPD(x) UA_UPD(y) UA_UPD(z) UA_UPD(w) }
+#undef UA_UPD
+        c_km = c_new;
+        if (lane == 0) s_c[m] = c_new;
+        __syncthreads();
+        float Ck = 0.f;
+        for (int i = 0; i < M; ++i) Ck += s_c[i];
+        pi_km = c_km / (Ck + 1e-10f);                                                  // :229-230
+        if (threadIdx.x == 0) {                                                        // :233
+            float gs = 0.f;
+            for (int b = 0; b < B; ++b) gs += G[(size_t)b * K + k];
+            a.class_counts[k] += gs;
+        }
+    }
+    if (a.nfit > 0) {
+        store_row<VEC>(r, a.mu, a.var, off, lane);
+        if (lane == 0) { a.c[k * M + m] = c_km; a.pi[k * M + m] = pi_km; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of the log-likelihood w.r.t. x: grad_x[b,d] = sum_{k,m} w[b,k,m] * (mu-x)/v.
+// grid (B, D/256), block 256: thread = one feature d, loop over the K*M rows (coalesced 1 KiB
+// row segments, state served from L2 / Infinity Cache).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gmm_loglik_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ x,
+                      const float* __restrict__ w, int KM, int D, float eps, float* __restrict__ gx) {
+    __shared__ float s_w[1024];
+    const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+    const float xv = x[(size_t)b * D + d];
+    double acc = 0.0;
+    for (int r0 = 0; r0 < KM; r0 += 1024) {
+        const int n = min(1024, KM - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) s_w[i] = w[(size_t)b * KM + r0 + i];
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {
+            const size_t o = (size_t)(r0 + i) * D + d;
+            const float v = reg_var(var[o], eps);
+            acc += (double)(s_w[i] * ((mu[o] - xv) / v));
+        }
+    }
+    gx[(size_t)b * D + d] = (float)acc;
+}
+
+template <typename F>
+int dispatch_vec(int D, F&& f) {
+    switch (D / 256) {
+        case 1: return f(std::integral_constant<int, 1>{});
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 3: return f(std::integral_constant<int, 3>{});
+        case 4: return f(std::integral_constant<int, 4>{});
+        case 5: return f(std::integral_constant<int, 5>{});
+        case 6: return f(std::integral_constant<int, 6>{});
+        case 7: return f(std::integral_constant<int, 7>{});
+        case 8: return f(std::integral_constant<int, 8>{});
+        default: return UA_EUNSUPPORTED;
+    }
+}
+
+int check_envelope(int K, int M, int D) {
+    if (K <= 0 || M <= 0 || D <= 0) return UA_EINVAL;
+    if (D % 256 != 0 || D > 2048 || M > kMaxModes) return UA_EUNSUPPORTED;
+    return UA_OK;
+}
+
+int launch_step(const StepArgs& a, int D, hipStream_t st) {
+    return dispatch_vec(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        hipLaunchKernelGGL(gmm_step_kernel<VEC>, dim3(a.K), dim3(a.M * 64), 0, st, a);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+}
+
+}  // namespace
+
+extern "C" int ua_gmm_loglik(const float* mu, const float* var, const float* pi, const float* x,
+                             int32_t B, int32_t K, int32_t M, int32_t D, float eps,
+                             float* scores, float* joint, float* loglik, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(x);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(var); UA_CHECK_ALIGN16(x);
+    if (B <= 0) return UA_EINVAL;
+    if (int e = check_envelope(K, M, D)) return e;
+    return dispatch_vec(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        dim3 grid(K, (B + kQChunk - 1) / kQChunk);
+        hipLaunchKernelGGL(gmm_loglik_kernel<VEC>, grid, dim3(M * 64), 0, ua::as_stream(stream),
+                           mu, var, pi, x, B, K, M, eps, scores, joint, loglik);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+}
+
+extern "C" int ua_gmm_loglik_bwd(const float* mu, const float* var, const float* x, const float* grad_ll,
+                                 int32_t B, int32_t K, int32_t M, int32_t D, float eps,
+                                 float* grad_x, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(x); UA_CHECK_PTR(grad_ll); UA_CHECK_PTR(grad_x);
+    if (B <= 0 || K <= 0 || M <= 0 || D <= 0) return UA_EINVAL;
+    if (D % 256 != 0) return UA_EUNSUPPORTED;
+    hipLaunchKernelGGL(gmm_loglik_bwd_kernel, dim3(B, D / 256), dim3(256), 0, ua::as_stream(stream),
+                       mu, var, x, grad_ll, K * M, D, eps, grad_x);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_gmm_fit(float* mu, float* var, float* pi, float* c, float* class_counts,
+                          const float* x, const float* gamma_class,
+                          int32_t B, int32_t K, int32_t M, int32_t D, float eps, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(c); UA_CHECK_PTR(class_counts);
+    UA_CHECK_PTR(x); UA_CHECK_PTR(gamma_class);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(var); UA_CHECK_ALIGN16(x);
+    if (B <= 0) return UA_EINVAL;
+    if (B > kMaxFitB) return UA_EUNSUPPORTED;
+    if (int e = check_envelope(K, M, D)) return e;
+    StepArgs a{};
+    a.mu = mu; a.var = var; a.pi = pi; a.c = c; a.class_counts = class_counts;
+    a.nq = 0; a.nfit = 1; a.xf[0] = x; a.gf[0] = gamma_class; a.bf[0] = B;
+    a.K = K; a.M = M; a.eps = eps;
+    return launch_step(a, D, ua::as_stream(stream));
+}
+
+extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_counts,
+                                 const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                                 const float* gamma_class, float* scores,
+                                 int32_t K, int32_t M, int32_t D, float eps, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(c); UA_CHECK_PTR(class_counts);
+    UA_CHECK_PTR(xq); UA_CHECK_PTR(x1); UA_CHECK_PTR(x2); UA_CHECK_PTR(gamma_class); UA_CHECK_PTR(scores);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(var); UA_CHECK_ALIGN16(xq); UA_CHECK_ALIGN16(x1); UA_CHECK_ALIGN16(x2);
+    if (int e = check_envelope(K, M, D)) return e;
+    StepArgs a{};
+    a.mu = mu; a.var = var; a.pi = pi; a.c = c; a.class_counts = class_counts;
+    a.xq = xq; a.nq = 1; a.round_q = xq_round_fp16; a.scores = scores;
+    a.nfit = 2; a.xf[0] = x1; a.xf[1] = x2; a.gf[0] = gamma_class; a.gf[1] = gamma_class; a.bf[0] = 1; a.bf[1] = 1;
+    a.K = K; a.M = M; a.eps = eps;
+    return launch_step(a, D, ua::as_stream(stream));
+}

@@ -1,0 +1,335 @@
+// Zero-shot logits, entropy-weighted fusion and the text-residual learning step for gfx950.
+//
+// Reference semantics: Uni_Adapter.py:21-26 (softmax_entropy), :53-75 (get_logits_wrapper),
+// :191-270 (compute_text_alignment_loss), :388-393 / :444-476 (text residuals + Adam),
+// :491-521 (fusion).  All of these are K- or K^2-sized (K = classes): latency-bound, so each is
+// one launch of one (or K) workgroups with wavefront reductions and no intermediate HBM traffic.
+#include "ua_common.h"
+
+namespace {
+
+using ua::block_sum;
+using ua::wave_sum;
+
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = ua::wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float t = scratch[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+// softmax over z[0..K) in LDS -> p (LDS), returns entropy -sum p ln(p+1e-10) (Uni_Adapter.py:21-26)
+__device__ float softmax_entropy_lds(const float* z, float* p, int K, double* sd, float* sf) {
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) mx = fmaxf(mx, z[i]);
+    mx = block_max(mx, sf);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) { const float e = expf(z[i] - mx); p[i] = e; s += (double)e; }
+    const float sum = (float)block_sum(s, sd);
+    double h = 0.0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const float pi = p[i] / sum;
+        p[i] = pi;
+        h += (double)(pi * logf(pi + 1e-10f));
+    }
+    return -(float)block_sum(h, sd);
+}
+
+// ------------------------------------------------------------------------------------------
+// get_logits_wrapper, one workgroup of 256 threads.  dynamic LDS: D + 2K floats.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+clip_logits_kernel(const float* __restrict__ feat, const float* __restrict__ text, int K, int D, float scale,
+                   int n_norm, float* __restrict__ fhat, float* __restrict__ logits, float* __restrict__ prob,
+                   float* __restrict__ entropy, int* __restrict__ pred) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    float* f = smem;          // D
+    float* z = smem + D;      // K
+    float* p = z + K;         // K
+    for (int i = threadIdx.x; i < D; i += 256) f[i] = feat[i];
+    __syncthreads();
+    for (int r = 0; r < n_norm; ++r) {                     // x / x.norm(dim=-1)   :56 (and :429)
+        double s = 0.0;
+        for (int i = threadIdx.x; i < D; i += 256) s += (double)(f[i] * f[i]);
+        const float nrm = (float)sqrt(block_sum(s, sd));
+        for (int i = threadIdx.x; i < D; i += 256) f[i] = f[i] / nrm;
+        __syncthreads();
+    }
+    if (fhat) for (int i = threadIdx.x; i < D; i += 256) fhat[i] = f[i];
+    if (!logits && !prob && !entropy && !pred) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = w; k < K; k += 4) {                      // (100*f) @ text^T          :57
+        const float4* t4 = reinterpret_cast<const float4*>(text + (size_t)k * D);
+        double acc = 0.0;
+        for (int i = lane; i < D / 4; i += 64) {
+            const float4 t = t4[i];
+            acc += (double)((scale * f[4 * i + 0]) * t.x) + (double)((scale * f[4 * i + 1]) * t.y)
+                 + (double)((scale * f[4 * i + 2]) * t.z) + (double)((scale * f[4 * i + 3]) * t.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) z[k] = (float)acc;
+    }
+    __syncthreads();
+    const float h = softmax_entropy_lds(z, p, K, sd, sf);
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256) {
+        if (logits) logits[i] = z[i];
+        if (prob) prob[i] = p[i];
+    }
+    if (threadIdx.x == 0) {
+        if (entropy) *entropy = h;
+        if (pred) { int b = 0; for (int i = 1; i < K; ++i) if (z[i] > z[b]) b = i; *pred = b; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fusion, one workgroup.  dynamic LDS: 3K floats.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fuse_logits_kernel(const float* __restrict__ clip, const float* __restrict__ dota, const float* __restrict__ c,
+                   int K, int M, float rho, float eta, int batch, const int* __restrict__ target,
+                   float* __restrict__ final_logits, int* __restrict__ rank, int* __restrict__ pred) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    float* zc = smem; float* zd = smem + K; float* p = smem + 2 * K;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < K * M; i += 256) s += (double)c[i];
+    const float cmean = (float)(block_sum(s, sd) / (double)(K * M));
+    const float w = fminf(rho * cmean / (float)batch, eta);                      // :491
+    for (int i = threadIdx.x; i < K; i += 256) { zc[i] = clip[i]; zd[i] = w * dota[i]; }   // :498
+    __syncthreads();
+    const float hc = softmax_entropy_lds(zc, p, K, sd, sf);                      // :508
+    __syncthreads();
+    const float hd = softmax_entropy_lds(zd, p, K, sd, sf);                      // :509
+    float wc = 1.f / (hc + 1e-3f);                                               // :510
+    float wd = 1.f / (hd + 1e-3f);                                               // :511
+    wc = wc / (wc + wd);                                                         // :512
+    wd = wd / (wc + wd);                                                         // :513 (reuses new wc)
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const float v = wc * zc[i] + wd * zd[i];                                 // :521
+        p[i] = v;
+        final_logits[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (pred) { int b = 0; for (int i = 1; i < K; ++i) if (p[i] > p[b]) b = i; *pred = b; }
+        if (rank && target) {
+            const int t = *target;
+            int rk = 0;
+            if (t >= 0 && t < K) { for (int i = 0; i < K; ++i) rk += (p[i] > p[t]) || (p[i] == p[t] && i < t); }
+            else rk = K;
+            *rank = rk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// e = (text0+res)/|text0+res|, one workgroup per class row.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+text_normalize_kernel(const float* __restrict__ text0, const float* __restrict__ res, int D, float clamp_eps,
+                      float* __restrict__ e, float* __restrict__ nrm_out) {
+    __shared__ double sd[16];
+    const size_t o = (size_t)blockIdx.x * D;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) { const float t = text0[o + i] + (res ? res[o + i] : 0.f); s += (double)(t * t); }
+    float n = (float)sqrt(block_sum(s, sd));
+    if (nrm_out && threadIdx.x == 0) nrm_out[blockIdx.x] = n;
+    n = fmaxf(n, clamp_eps);
+    for (int i = threadIdx.x; i < D; i += 256) e[o + i] = (text0[o + i] + (res ? res[o + i] : 0.f)) / n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Alignment loss + gradient w.r.t. the per-mode log-likelihoods, one workgroup of 1024.
+//   Ln = L/max(L); P = exp(exp(Ln)); loss = -mean(diag P / rowsum) - mean(diag P / colsum)
+// dynamic LDS: K*K (P) + 4K floats.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+align_loss_kernel(const float* __restrict__ L, const float* __restrict__ joint, int K, int M,
+                  float* __restrict__ loss_out, float* __restrict__ grad_ll) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    __shared__ int s_arg;
+    float* P = smem;                 // K*K
+    float* s1 = smem + K * K;        // row sums
+    float* s2 = s1 + K;              // col sums
+    float* dg = s2 + K;              // diagonal
+    const int n = K * K, tid = threadIdx.x, nt = blockDim.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += nt) mx = fmaxf(mx, L[i]);
+    mx = block_max(mx, sf);
+    if (tid == 0) s_arg = n;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) if (L[i] == mx) atomicMin(&s_arg, i);      // first arg-max
+    for (int i = tid; i < n; i += nt) P[i] = expf(expf(L[i] / mx));              // :248-249
+    __syncthreads();
+    for (int r = tid; r < 2 * K; r += nt) {                                      // :251-252
+        double s = 0.0;
+        if (r < K) { for (int j = 0; j < K; ++j) s += (double)P[r * K + j]; s1[r] = (float)s; }
+        else { const int cidx = r - K; for (int j = 0; j < K; ++j) s += (double)P[j * K + cidx]; s2[cidx] = (float)s; }
+    }
+    for (int i = tid; i < K; i += nt) dg[i] = P[i * K + i];
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < K; i += nt) part += (double)(dg[i] / s1[i]) + (double)(dg[i] / s2[i]);
+    const double tot = block_sum(part, sd);
+    if (tid == 0 && loss_out) *loss_out = (float)(-tot / (double)K);             // :253
+    if (!grad_ll) return;
+    // dLoss/dP -> dLoss/dLn ; S = sum dLn * L (for the max() path)
+    const float invK = 1.f / (float)K;
+    double sacc = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        const int r = i / K, cidx = i % K;
+        const float eye = (r == cidx) ? 1.f : 0.f;
+        const float dP = -invK * (eye / s1[r] - dg[r] / (s1[r] * s1[r])) - invK * (eye / s2[cidx] - dg[cidx] / (s2[cidx] * s2[cidx]));
+        const float l = L[i];
+        const float E = expf(l / mx);
+        const float dLn = dP * P[i] * E;
+        sacc += (double)dLn * (double)l;
+        P[i] = dLn;                                  // reuse LDS: P now holds dLoss/dLn
+    }
+    const double S = block_sum(sacc, sd);
+    __syncthreads();
+    const int amax = s_arg;
+    const int nm = n * M;
+    for (int i = tid; i < nm; i += nt) {
+        const int ik = i / M;
+        float G = P[ik] / mx;
+        if (ik == amax) G += (float)(-S / ((double)mx * (double)mx));
+        grad_ll[i] = G * expf(joint[i] - L[ik]);     // d logsumexp / d joint = softmax
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grad_e -> grad_t through e = t/|t|, one Adam step on res, refresh e and |t|.
+// One workgroup per class row.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+residual_adam_kernel(const float* __restrict__ text0, float* __restrict__ res, float* __restrict__ am,
+                     float* __restrict__ av, const float* __restrict__ ge, float* __restrict__ e,
+                     float* __restrict__ nrm, int D, float step_size, float w1, float beta2, float omb2,
+                     float bc2_sqrt, float adam_eps) {
+    __shared__ double sd[16];
+    const int k = blockIdx.x;
+    const size_t o = (size_t)k * D;
+    const float n = nrm[k];
+    double dot = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) dot += (double)(ge[o + i] * e[o + i]);
+    const float gdote = (float)block_sum(dot, sd);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float g = (ge[o + i] - e[o + i] * gdote) / n;          // d(t/|t|)/dt applied to grad_e
+        float m = am[o + i], v = av[o + i];
+        m = m + w1 * (g - m);                                        // exp_avg.lerp_(grad, 1-beta1)
+        v = v * beta2 + omb2 * (g * g);                              // mul_(beta2).addcmul_(g,g,1-beta2)
+        const float den = sqrtf(v) / bc2_sqrt + adam_eps;
+        const float r = res[o + i] + ((-step_size) * m) / den;       // addcdiv_(m, den, value=-step_size)
+        am[o + i] = m; av[o + i] = v; res[o + i] = r;
+        const float t = text0[o + i] + r;
+        s += (double)(t * t);
+    }
+    const float nn = (float)sqrt(block_sum(s, sd));
+    if (threadIdx.x == 0) nrm[k] = nn;
+    for (int i = threadIdx.x; i < D; i += 256) e[o + i] = (text0[o + i] + res[o + i]) / nn;
+}
+
+}  // namespace
+
+extern "C" int ua_clip_logits(const float* feat, const float* text, int32_t K, int32_t D, float scale,
+                              int32_t n_normalize, float* fhat, float* logits, float* prob, float* entropy,
+                              int32_t* pred, void* stream) {
+    UA_CHECK_PTR(feat); UA_CHECK_PTR(text); UA_CHECK_ALIGN16(text);
+    if (K <= 0 || D <= 0 || n_normalize < 0) return UA_EINVAL;
+    if (D % 4 != 0) return UA_EUNSUPPORTED;
+    const size_t lds = (size_t)(D + 2 * K) * sizeof(float);
+    if (lds > 150 * 1024) return UA_EUNSUPPORTED;
+    hipLaunchKernelGGL(clip_logits_kernel, dim3(1), dim3(256), lds, ua::as_stream(stream),
+                       feat, text, K, D, scale, n_normalize, fhat, logits, prob, entropy, pred);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_fuse_logits(const float* clip_logits, const float* dota_logits, const float* c,
+                              int32_t K, int32_t M, float rho, float eta, int32_t batch,
+                              const int32_t* target, float* final_logits, int32_t* rank, int32_t* pred,
+                              void* stream) {
+    UA_CHECK_PTR(clip_logits); UA_CHECK_PTR(dota_logits); UA_CHECK_PTR(c); UA_CHECK_PTR(final_logits);
+    if (K <= 0 || M <= 0 || batch <= 0) return UA_EINVAL;
+    const size_t lds = (size_t)(3 * K) * sizeof(float);
+    if (lds > 150 * 1024) return UA_EUNSUPPORTED;
+    hipLaunchKernelGGL(fuse_logits_kernel, dim3(1), dim3(256), lds, ua::as_stream(stream),
+                       clip_logits, dota_logits, c, K, M, rho, eta, batch, target, final_logits, rank, pred);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_text_normalize(const float* text0, const float* res, int32_t K, int32_t D, float clamp_eps,
+                                 float* e_out, float* norm_out, void* stream) {
+    UA_CHECK_PTR(text0); UA_CHECK_PTR(e_out);
+    if (K <= 0 || D <= 0) return UA_EINVAL;
+    hipLaunchKernelGGL(text_normalize_kernel, dim3(K), dim3(256), 0, ua::as_stream(stream),
+                       text0, res, D, clamp_eps, e_out, norm_out);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_align_loss(const float* L, const float* joint, int32_t K, int32_t M,
+                             float* loss_out, float* grad_ll, void* stream) {
+    UA_CHECK_PTR(L);
+    if (K <= 0 || M <= 0) return UA_EINVAL;
+    if (grad_ll && !joint) return UA_EINVAL;
+    if (K > 160) return UA_EUNSUPPORTED;
+    const size_t lds = (size_t)(K * K + 4 * K) * sizeof(float);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(align_loss_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return UA_ELAUNCH;
+    hipLaunchKernelGGL(align_loss_kernel, dim3(1), dim3(1024), lds, ua::as_stream(stream),
+                       L, joint, K, M, loss_out, grad_ll);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_residual_adam(const float* text0, float* res, float* adam_m, float* adam_v,
+                                const float* grad_e, float* e, float* norm,
+                                int32_t K, int32_t D, int32_t step, double lr, double beta1, double beta2,
+                                double adam_eps, void* stream) {
+    UA_CHECK_PTR(text0); UA_CHECK_PTR(res); UA_CHECK_PTR(adam_m); UA_CHECK_PTR(adam_v);
+    UA_CHECK_PTR(grad_e); UA_CHECK_PTR(e); UA_CHECK_PTR(norm);
+    if (K <= 0 || D <= 0 || step <= 0) return UA_EINVAL;
+    // scalar bookkeeping exactly as torch.optim.adam._single_tensor_adam (python floats = double)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1);
+    const float omb2 = (float)(1.0 - beta2);
+    hipLaunchKernelGGL(residual_adam_kernel, dim3(K), dim3(256), 0, ua::as_stream(stream),
+                       text0, res, adam_m, adam_v, grad_e, e, norm, D, step_size, w1, (float)beta2, omb2,
+                       bc2_sqrt, (float)adam_eps);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_version(void) { return UA_VERSION; }
+
+extern "C" const char* ua_strerror(int code) {
+    switch (code) {
+        case UA_OK: return "ok";
+        case UA_EINVAL: return "invalid argument (null pointer or bad shape)";
+        case UA_EALIGN: return "pointer or leading dimension not 16-byte aligned";
+        case UA_EUNSUPPORTED: return "shape outside the compiled envelope";
+        case UA_EWORKSPACE: return "workspace too small";
+        case UA_ELAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}

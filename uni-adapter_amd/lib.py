@@ -1,0 +1,94 @@
+"""ctypes binding of libuniadapter_hip.so (include/uniadapter.h).
+
+The product path has NO fallback: if the library is missing this module raises at import, and
+every wrapper raises RuntimeError(ua_strerror(code)) on a non-zero return.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libuniadapter_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} not found: build it with `python uni-adapter_amd/csrc/build.py` '
+        '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the hot path.')
+
+_lib = C.CDLL(LIB_PATH)
+
+_p, _i32, _i64, _f, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class GemmEpilogue(C.Structure):
+    """ua_gemm_epilogue (include/uniadapter.h)."""
+    _fields_ = [('bias', _p), ('scale', _p), ('shift', _p),
+                ('rowgroup_add', _p), ('ldg', _i64), ('group_rows', _i32),
+                ('act', _i32),
+                ('residual', _p), ('ldr', _i64),
+                ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32)]
+
+
+# name -> argtypes, exactly the declarations of include/uniadapter.h
+SIGNATURES = {
+    'ua_gmm_loglik': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p],
+    'ua_gmm_loglik_bwd': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p],
+    'ua_gmm_fit': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p],
+    'ua_gmm_step_fused': [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p],
+    'ua_clip_logits': [_p, _p, _i32, _i32, _f, _i32, _p, _p, _p, _p, _p, _p],
+    'ua_fuse_logits': [_p, _p, _p, _i32, _i32, _f, _f, _i32, _p, _p, _p, _p, _p],
+    'ua_text_normalize': [_p, _p, _i32, _i32, _f, _p, _p, _p],
+    'ua_align_loss': [_p, _p, _i32, _i32, _p, _p, _p],
+    'ua_residual_adam': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _d, _d, _d, _d, _p],
+    'ua_fps': [_p, _i32, _i32, _i32, _i32, _f, _p, _p, _p],
+    'ua_knn_group': [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p],
+    'ua_gemm': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
+    'ua_layernorm': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _p],
+    'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(_lib, _name)       # AttributeError here = header and library out of sync
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+_lib.ua_version.restype = C.c_int
+_lib.ua_strerror.restype = C.c_char_p
+_lib.ua_strerror.argtypes = [C.c_int]
+
+
+def version():
+    return _lib.ua_version()
+
+
+def strerror(code):
+    return _lib.ua_strerror(code).decode()
+
+
+def _check(code, name):
+    if code != 0:
+        raise RuntimeError(f'{name}: {strerror(code)} (code {code})')
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, dtype=torch.float32, allow_none=False):
+    """Raw device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError('tensor required')
+    if not t.is_cuda:
+        raise RuntimeError('uni_adapter_amd kernels need tensors on a HIP device (no CPU fallback)')
+    if t.dtype != dtype:
+        raise TypeError(f'expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError('tensor must be contiguous')
+    return t.data_ptr()
+
+
+def call(name, *args):
+    _check(getattr(_lib, name)(*args), name)

@@ -1,0 +1,314 @@
+"""Uni3D point-cloud encoder on MI355X: drop-in for the reference `models/uni3d.py:Uni3D` /
+`models/point_encoder.py:PointcloudEncoder` call surface (`model.eval()`,
+`model.encode_pc(pc[B,N,6]) -> (B,embed_dim)`), weights taken from a reference-layout
+state_dict (keys after stripping `module.`, utils/load_models.py:56-59).
+
+Host code only prepares weights once (fusing q/k/v, interleaving the SwiGLU halves, padding K to
+the GEMM granularity) and enqueues kernels of libuniadapter_hip.so; all arithmetic of the forward
+runs in hand-written HIP (see include/uniadapter.h).  No CPU path.
+
+Token layout used on device: patch token g of cloud b is row b*G+g, the CLS token of cloud b is
+row Bc*G+b, so every big GEMM sees Bc*G (a multiple of 128) rows plus one thin tile of CLS rows.
+"""
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import lib
+from .lib import GemmEpilogue
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWIGLU = 0, 1, 2, 3
+
+
+class GemmProfiler:
+    """Optional per-launch HIP-event timing of ua_gemm (bench.py roofline leg).  Events are
+    recorded on the stream the kernel is launched on; read with `.summary()` after a sync."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        flops = sum(r[2] for r in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        return dict(launches=len(self.records), flops=flops, ms=ms)
+
+
+PROFILER = None          # set to a GemmProfiler to time every GEMM launch
+
+
+def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgroup_add=None, ldg=0,
+          group_rows=0, act=0, residual=None, ldr=0, pool_out=None, ldp=0, pool_rows=0, alg_flops=None):
+    """C (M,N) = A (M,K) @ W (N,K)^T + epilogue; all tensors already on device, fp32.
+    `alg_flops`: algorithmic FLOPs of the launch when K/N carry zero padding (default 2MNK)."""
+    e = GemmEpilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.scale = scale.data_ptr() if scale is not None else None
+    e.shift = shift.data_ptr() if shift is not None else None
+    e.rowgroup_add = rowgroup_add.data_ptr() if rowgroup_add is not None else None
+    e.ldg, e.group_rows, e.act = ldg, group_rows, act
+    e.residual = residual.data_ptr() if residual is not None else None
+    e.ldr = ldr
+    e.pool_out = pool_out.data_ptr() if pool_out is not None else None
+    e.ldp, e.pool_rows = ldp, pool_rows
+    prof = PROFILER
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    lib.call('ua_gemm', A.data_ptr(), lda, W.data_ptr(), W.stride(0), out.data_ptr() if out is not None else None,
+             ldc, M, N, K, C.byref(e), lib.stream_ptr())
+    if prof is not None:
+        ev1.record()
+        prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K))
+
+
+def _ln(x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad):
+    lib.call('ua_layernorm', x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), ldy,
+             rows, cols, cols_pad, lib.stream_ptr())
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Block:
+    """Prepared weights of one transformer block (timm EvaBlock / ViT Block layouts)."""
+    pass
+
+
+class PointcloudEncoder(nn.Module):
+    """Mirror of models/point_encoder.py:161-223 with the timm blocks folded in."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_group: int, group_size: int, num_heads: int,
+                 device=None, prefix: str = 'point_encoder.', ln_eps: float = 1e-6, bn_eps: float = 1e-5,
+                 fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError('uni_adapter_amd.PointcloudEncoder needs a HIP device (MI355X); no CPU path')
+        self.dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.num_group, self.group_size, self.num_heads = int(num_group), int(group_size), int(num_heads)
+        self.ln_eps, self.fps_start, self.fps_skip_eps = float(ln_eps), int(fps_start), float(fps_skip_eps)
+        self.pe_clouds = int(pe_clouds)
+        if self.group_size != 64:
+            raise NotImplementedError('patch-embed max-pool epilogue is built for group_size 64 (Uni3D)')
+        sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        d = lambda t: t.detach().to(self.dev, torch.float32).contiguous()
+
+        def bn_affine(name):                       # eval BatchNorm1d -> per-channel scale/shift
+            w, b = sd[name + '.weight'].double(), sd[name + '.bias'].double()
+            rm, rv = sd[name + '.running_mean'].double(), sd[name + '.running_var'].double()
+            s = w / torch.sqrt(rv + bn_eps)
+            return d(s), d(b - rm * s)
+
+        # ---- mini-PointNet (models/point_encoder.py:133-144) ----
+        w1 = sd['encoder.first_conv.0.weight'][:, :, 0]
+        self.in_ch = w1.shape[1]
+        self.w1 = d(torch.nn.functional.pad(w1.float(), (0, 8 - self.in_ch)))             # K padded 6 -> 8
+        self.b1 = d(sd['encoder.first_conv.0.bias'])
+        self.bn1_s, self.bn1_t = bn_affine('encoder.first_conv.1')
+        self.w2 = d(sd['encoder.first_conv.3.weight'][:, :, 0]); self.b2 = d(sd['encoder.first_conv.3.bias'])
+        w3 = sd['encoder.second_conv.0.weight'][:, :, 0]
+        self.c_loc = self.w2.shape[0]                                             # 256
+        self.w3g = d(w3[:, :self.c_loc]); self.w3l = d(w3[:, self.c_loc:])        # [global | local] halves
+        self.b3 = d(sd['encoder.second_conv.0.bias'])
+        self.bn2_s, self.bn2_t = bn_affine('encoder.second_conv.1')
+        self.w4 = d(sd['encoder.second_conv.3.weight'][:, :, 0]); self.b4 = d(sd['encoder.second_conv.3.bias'])
+        self.enc_dim = self.w4.shape[0]
+        # ---- bridges / positional MLP (:175-186) ----
+        self.w_e2t = d(sd['encoder2trans.weight']); self.b_e2t = d(sd['encoder2trans.bias'])
+        self.trans_dim = self.w_e2t.shape[0]
+        self.w_t2e = d(sd['trans2embed.weight']); self.b_t2e = d(sd['trans2embed.bias'])
+        self.embed_dim = self.w_t2e.shape[0]
+        self.w_p0 = d(torch.nn.functional.pad(sd['pos_embed.0.weight'], (0, 1))); self.b_p0 = d(sd['pos_embed.0.bias'])
+        self.w_p2 = d(sd['pos_embed.2.weight']); self.b_p2 = d(sd['pos_embed.2.bias'])
+        self.cls_token = d(sd['cls_token'].reshape(-1)); self.cls_pos = d(sd['cls_pos'].reshape(-1))
+        Cd = self.trans_dim
+        if Cd % self.num_heads or Cd // self.num_heads != 64:
+            raise NotImplementedError('attention kernel is built for head_dim 64')
+        # ---- transformer blocks (timm EvaBlock, key-driven) ----
+        n_blocks = 1 + max([int(k.split('.')[2]) for k in sd if k.startswith('visual.blocks.')], default=-1)
+        self.blocks = []
+        for i in range(n_blocks):
+            p = f'visual.blocks.{i}.'
+            has = lambda k: (p + k) in sd
+            g = lambda k: sd[p + k].detach().to(self.dev, torch.float32)
+            b = _Block()
+            b.n1w, b.n1b, b.n2w, b.n2b = d(g('norm1.weight')), d(g('norm1.bias')), d(g('norm2.weight')), d(g('norm2.bias'))
+            zeros = torch.zeros(Cd, device=self.dev)
+            if has('attn.q_proj.weight'):
+                wq, wk, wv = g('attn.q_proj.weight'), g('attn.k_proj.weight'), g('attn.v_proj.weight')
+                bq = g('attn.q_proj.bias') if has('attn.q_proj.bias') else zeros
+                bk = g('attn.k_proj.bias') if has('attn.k_proj.bias') else zeros
+                bv = g('attn.v_proj.bias') if has('attn.v_proj.bias') else zeros
+                wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
+            else:
+                wqkv = g('attn.qkv.weight')
+                bqkv = g('attn.qkv.bias') if has('attn.qkv.bias') else torch.zeros(3 * Cd, device=self.dev)
+            if has('attn.q_bias'):
+                bqkv = bqkv + torch.cat([g('attn.q_bias'), zeros, g('attn.v_bias') if has('attn.v_bias') else zeros], 0)
+            b.wqkv, b.bqkv = d(wqkv), d(bqkv)
+            b.an_w, b.an_b = (d(g('attn.norm.weight')), d(g('attn.norm.bias'))) if has('attn.norm.weight') else (None, None)
+            b.wproj, b.bproj = d(g('attn.proj.weight')), d(g('attn.proj.bias'))
+            b.gamma1 = d(g('gamma_1')) if has('gamma_1') else None
+            b.gamma2 = d(g('gamma_2')) if has('gamma_2') else None
+            if has('mlp.fc1_g.weight'):                                  # SwiGLU: interleave 32-col blocks
+                wg, wx = g('mlp.fc1_g.weight'), g('mlp.fc1_x.weight')
+                bg, bx = g('mlp.fc1_g.bias'), g('mlp.fc1_x.bias')
+                H = wg.shape[0]; Hp = _round_up(H, 32)
+                padr = lambda t: torch.nn.functional.pad(t, (0, 0, 0, Hp - H)) if t.dim() == 2 else torch.nn.functional.pad(t, (0, Hp - H))
+                wg, wx, bg, bx = padr(wg), padr(wx), padr(bg), padr(bx)
+                b.w1 = d(torch.stack([wg.reshape(Hp // 32, 32, Cd), wx.reshape(Hp // 32, 32, Cd)], 1).reshape(2 * Hp, Cd))
+                b.b1 = d(torch.stack([bg.reshape(Hp // 32, 32), bx.reshape(Hp // 32, 32)], 1).reshape(2 * Hp))
+                b.act = ACT_SWIGLU
+            else:                                                         # plain GELU MLP
+                w1_, b1_ = g('mlp.fc1.weight'), g('mlp.fc1.bias')
+                H = w1_.shape[0]; Hp = _round_up(H, 32)
+                b.w1 = d(torch.nn.functional.pad(w1_, (0, 0, 0, Hp - H))); b.b1 = d(torch.nn.functional.pad(b1_, (0, Hp - H)))
+                b.act = ACT_GELU
+            b.H, b.Hp = H, Hp
+            b.mn_w, b.mn_b = (d(g('mlp.norm.weight')), d(g('mlp.norm.bias'))) if has('mlp.norm.weight') else (None, None)
+            b.w2 = d(torch.nn.functional.pad(g('mlp.fc2.weight'), (0, Hp - H))); b.b2 = d(g('mlp.fc2.bias'))
+            self.blocks.append(b)
+        self.norm = (d(sd['visual.norm.weight']), d(sd['visual.norm.bias'])) if 'visual.norm.weight' in sd else None
+        self.fc_norm = (d(sd['visual.fc_norm.weight']), d(sd['visual.fc_norm.bias'])) if 'visual.fc_norm.weight' in sd else None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, Bc):
+        ws = self._ws.get(Bc)
+        if ws is not None:
+            return ws
+        G, S, Cd = self.num_group, self.group_size, self.trans_dim
+        pc = min(self.pe_clouds, Bc)
+        Mp = pc * G * S
+        rows = Bc * G + Bc
+        Hp = max(b.Hp for b in self.blocks) if self.blocks else 32
+        e = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
+        ws = dict(
+            centers=e(Bc, G, 3), centers4=torch.zeros(Bc * G, 4, device=self.dev), feat=e(Mp, 8),
+            h1=e(Mp, 128), loc=e(Mp, self.c_loc), glob=e(pc * G, self.c_loc), g3=e(pc * G, self.w3g.shape[0]),
+            h3=e(Mp, self.w3l.shape[0]), tok=e(Bc * G, self.enc_dim), tokc=e(Bc * G, Cd), posh=e(Bc * G, 128),
+            pos=e(Bc * G, Cd), x=e(rows, Cd), h=e(rows, Cd), qkv=e(rows, 3 * Cd), att=e(rows, Cd),
+            hid=e(rows, Hp), hidn=e(rows, Hp), cls=e(Bc, Cd), cls2=e(Bc, Cd), out=e(Bc, self.embed_dim))
+        self._ws[Bc] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, pts, colors, return_tokens=False):
+        """pts, colors: (Bc,N,3) fp32 on device -> (Bc, embed_dim)  (models/point_encoder.py:192-223)."""
+        Bc, N, _ = pts.shape
+        G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
+        pts = pts.to(self.dev, torch.float32).contiguous()
+        colors = colors.to(self.dev, torch.float32).contiguous()
+        w = self._workspace(Bc)
+        st = lib.stream_ptr()
+        # ---- grouping (:108-127) ----
+        lib.call('ua_fps', pts.data_ptr(), Bc, N, G, self.fps_start, self.fps_skip_eps, None, w['centers'].data_ptr(), st)
+        w['centers4'][:, :3].copy_(w['centers'].view(-1, 3))
+        # ---- mini-PointNet per chunk of clouds (:145-159) ----
+        pc = min(self.pe_clouds, Bc)
+        for c0 in range(0, Bc, pc):
+            nb = min(pc, Bc - c0)
+            Mp, Mg = nb * G * S, nb * G
+            lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr(), w['centers'][c0:].data_ptr(),
+                     nb, N, G, S, w['feat'].data_ptr(), 8, None, st)
+            _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
+                  alg_flops=2.0 * Mp * 128 * self.in_ch)
+            _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
+                  pool_out=w['glob'], ldp=self.c_loc, pool_rows=64)
+            n3 = self.w3g.shape[0]
+            _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
+            _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
+                  group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
+            _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
+                  pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
+        # ---- token assembly (:198-208) ----
+        Mg = Bc * G
+        _gemm(w['tok'], self.enc_dim, self.w_e2t, w['tokc'], Cd, Mg, Cd, self.enc_dim, bias=self.b_e2t)
+        _gemm(w['centers4'], 4, self.w_p0, w['posh'], 128, Mg, 128, 4, bias=self.b_p0, act=ACT_GELU, alg_flops=2.0 * Mg * 128 * 3)
+        _gemm(w['posh'], 128, self.w_p2, w['pos'], Cd, Mg, Cd, 128, bias=self.b_p2)
+        lib.call('ua_assemble_tokens', w['tokc'].data_ptr(), w['pos'].data_ptr(), self.cls_token.data_ptr(),
+                 self.cls_pos.data_ptr(), w['x'].data_ptr(), Bc, G, Cd, st)
+        # ---- transformer blocks (:217-218) ----
+        rows = Mg + Bc
+        x = w['x']
+        for b in self.blocks:
+            _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+            _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv)
+            lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
+            att = w['att']
+            if b.an_w is not None:
+                _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+                att = w['h']
+            _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd)
+            _ln(x, Cd, b.n2w, b.n2b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+            Hp = b.Hp
+            ld_h = w['hid'].stride(0)
+            if b.act == ACT_SWIGLU:
+                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, 2 * Hp, Cd, bias=b.b1, act=ACT_SWIGLU, alg_flops=4.0 * rows * b.H * Cd)
+            else:
+                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, Hp, Cd, bias=b.b1, act=ACT_GELU, alg_flops=2.0 * rows * b.H * Cd)
+            hid = w['hid']
+            if b.mn_w is not None:
+                _ln(w['hid'], ld_h, b.mn_w, b.mn_b, self.ln_eps, w['hidn'], ld_h, rows, b.H, Hp)
+                hid = w['hidn']
+            _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H)
+        # ---- head (:219-222) on the CLS rows ----
+        cls = x[Mg:]
+        cur, nxt = cls, w['cls']
+        for nrm in (self.norm, self.fc_norm):
+            if nrm is not None:
+                _ln(cur, Cd, nrm[0], nrm[1], self.ln_eps, nxt, Cd, Bc, Cd, Cd)
+                cur, nxt = nxt, (w['cls2'] if nxt is w['cls'] else w['cls'])
+        out = torch.empty(Bc, self.embed_dim, device=self.dev, dtype=torch.float32)
+        _gemm(cur, Cd, self.w_t2e, out, self.embed_dim, Bc, self.embed_dim, Cd, bias=self.b_t2e)
+        if return_tokens:
+            # reference token order: [cls, patch tokens] per cloud
+            tokens = torch.cat([x[Mg:].view(Bc, 1, Cd), x[:Mg].view(Bc, G, Cd)], 1)
+            return out, tokens
+        return out
+
+    def flops_per_cloud(self):
+        """Algorithmic FLOPs of one forward (SURVEY section 8d bookkeeping, reference formulation)."""
+        G, S, Cd = self.num_group, self.group_size, self.trans_dim
+        T = G + 1
+        f = G * S * 2 * (self.in_ch * 128 + 128 * self.c_loc + (2 * self.c_loc) * self.w3l.shape[0] + self.w3l.shape[0] * self.enc_dim)
+        f += G * 2 * (self.enc_dim * Cd + 3 * 128 + 128 * Cd)
+        for b in self.blocks:
+            f += 2 * T * Cd * Cd * 4 + 4 * T * T * Cd
+            f += 2 * T * Cd * b.H * (3 if b.act == ACT_SWIGLU else 2)
+        f += 2 * Cd * self.embed_dim
+        return f
+
+
+class Uni3D(nn.Module):
+    """Mirror of models/uni3d.py:9-28 (`encode_pc`)."""
+
+    def __init__(self, point_encoder: PointcloudEncoder, logit_scale: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.point_encoder = point_encoder
+        self.logit_scale = logit_scale if logit_scale is not None else torch.ones([]) * math.log(1 / 0.07)
+
+    def encode_pc(self, pc):
+        xyz = pc[:, :, :3].contiguous()
+        color = pc[:, :, 3:].contiguous()
+        return self.point_encoder(xyz, color)
+
+    def forward(self, pc, text, image):
+        return {'text_embed': text, 'pc_embed': self.encode_pc(pc), 'image_embed': image,
+                'logit_scale': self.logit_scale.exp()}
+
+
+def create_uni3d_from_state_dict(state_dict, args=None, num_group=None, group_size=None, num_heads=None, **kw):
+    """Build the model from a Uni3D checkpoint's `module` dict (utils/load_models.py:53-61) or a
+    synthetic state_dict of the same layout.  `args` follows utils/params.py:35-43."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+    num_group = num_group or getattr(args, 'num_group', None) or getattr(args, 'num_group_uni3d', 512)
+    group_size = group_size or getattr(args, 'group_size', None) or getattr(args, 'group_size_uni3d', 64)
+    trans_dim = sd['point_encoder.encoder2trans.weight'].shape[0]
+    num_heads = num_heads or trans_dim // 64
+    enc = PointcloudEncoder(sd, num_group, group_size, num_heads, **kw)
+    return Uni3D(enc, sd.get('logit_scale'))

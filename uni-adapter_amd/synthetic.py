@@ -1,0 +1,59 @@
+"""Synthetic inputs of the reference's shapes for bench.py / smoke tests (there are no datasets or
+checkpoints offline): Uni3D-layout random weights, unit-sphere point clouds, text banks.
+Shapes: models/point_encoder.py:129-186, timm eva02_large_patch14_448 (SURVEY section 8 cfg table)."""
+import math
+
+import torch
+
+
+def uni3d_state_dict(seed=0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=24, hidden=None, in_ch=6,
+                     device='cpu', std=0.02):
+    """Random-init weights in the reference state-dict key layout (utils/load_models.py:56-59)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    C = trans_dim
+    H = hidden if hidden is not None else int(trans_dim * 8 / 3)
+    P = 'point_encoder.'
+    sd = {}
+    rn = lambda *s, scale=1.0: torch.randn(*s, generator=g, device=device) * scale
+
+    def lin(name, co, ci):
+        sd[P + name + '.weight'] = rn(co, ci, scale=1 / math.sqrt(ci)); sd[P + name + '.bias'] = rn(co, scale=std)
+
+    def ln(name, c):
+        sd[P + name + '.weight'] = 1 + rn(c, scale=0.05); sd[P + name + '.bias'] = rn(c, scale=0.05)
+
+    def conv(name, co, ci):
+        sd[P + name + '.weight'] = rn(co, ci, 1, scale=1 / math.sqrt(ci)); sd[P + name + '.bias'] = rn(co, scale=std)
+
+    def bn(name, c):
+        sd[P + name + '.weight'] = 1 + rn(c, scale=0.1); sd[P + name + '.bias'] = rn(c, scale=0.1)
+        sd[P + name + '.running_mean'] = rn(c, scale=0.1)
+        sd[P + name + '.running_var'] = 1 + 0.2 * torch.rand(c, generator=g, device=device)
+
+    conv('encoder.first_conv.0', 128, in_ch); bn('encoder.first_conv.1', 128); conv('encoder.first_conv.3', 256, 128)
+    conv('encoder.second_conv.0', 512, 512); bn('encoder.second_conv.1', 512); conv('encoder.second_conv.3', enc_dim, 512)
+    lin('encoder2trans', C, enc_dim); lin('trans2embed', embed_dim, C)
+    sd[P + 'cls_token'] = rn(1, 1, C, scale=std); sd[P + 'cls_pos'] = rn(1, 1, C, scale=0.1)
+    lin('pos_embed.0', 128, 3); lin('pos_embed.2', C, 128)
+    for i in range(depth):
+        b = f'visual.blocks.{i}.'
+        ln(b + 'norm1', C); ln(b + 'norm2', C)
+        lin(b + 'attn.q_proj', C, C); lin(b + 'attn.v_proj', C, C); lin(b + 'attn.proj', C, C)
+        sd[P + b + 'attn.k_proj.weight'] = rn(C, C, scale=1 / math.sqrt(C))
+        lin(b + 'mlp.fc1_g', H, C); lin(b + 'mlp.fc1_x', H, C); ln(b + 'mlp.norm', H); lin(b + 'mlp.fc2', C, H)
+    ln('visual.fc_norm', C)
+    sd['logit_scale'] = torch.tensor(math.log(1 / 0.07), device=device)
+    return sd
+
+
+def point_clouds(n, n_points=1024, seed=42, device='cpu'):
+    """randn clouds scaled into the unit sphere, rgb = ones (data/tta_datasets.py:127)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    xyz = torch.randn(n, n_points, 3, generator=g, device=device)
+    xyz = xyz / xyz.norm(dim=-1).amax(dim=1)[:, None, None]
+    return xyz, torch.ones(n, n_points, 3, device=device)
+
+
+def text_bank(K, D, seed=0, device='cpu'):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.nn.functional.normalize(torch.randn(K, D, generator=g, device=device), dim=1)
