@@ -37,6 +37,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), de
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 
 
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,7 +96,9 @@ def similarity_roofline(dev):
 def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
     """Oracle (kind 'port') timed on the host cores on the first n samples of the same stream."""
     from oracle import ref_cpu as O               # baseline leg only
-    torch.set_num_threads(os.cpu_count())
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get('UA_CPU_THREADS', ncpu)))))
+    log(f'cpu baseline: {torch.get_num_threads()} threads, {n} samples')
     s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
     enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
     t_enc = t_cache = 0.0
@@ -107,6 +113,7 @@ def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
         b = time.perf_counter()
         s.step(f, fa)
         t_enc += b - a; t_cache += time.perf_counter() - b
+        log(f'cpu sample {i}: enc {b - a:.2f}s cache {time.perf_counter() - b:.2f}s')
     dt = time.perf_counter() - t0
     return {'value': round(n / dt, 4), 'unit': 'point-clouds/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'first {n} samples of the same synthetic stream (2 encoder forwards + cache step + residual learning each); '
@@ -154,8 +161,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    log('model + stream resident; warm-up')
     for i in range(a.warmup):
         step(i)
+        torch.cuda.synchronize(); log(f'warm-up step {i} done')
     prof = PE.GemmProfiler()
     fence()
     PE.PROFILER = prof
@@ -170,6 +179,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     samples = n_global * a.steps
+    log(f'timed region: {dt:.3f}s for {samples} samples')
     gsum = prof.summary()
     tfl = gsum['flops'] / (gsum['ms'] * 1e-3) / 1e12 if gsum['ms'] > 0 else 0.0
     out = {

@@ -181,6 +181,32 @@ int ua_assemble_tokens(const float* tok, const float* pos, const float* cls_toke
                        const float* cls_pos, float* x, int32_t Bc, int32_t G, int32_t C,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Composite: the in-order cache replay of a chunk of samples in ONE host call
+ * (Uni_Adapter.py:388-521 per sample: clip logits -> predict+fit+fit -> [sample index > 0:
+ * res_steps x (alignment forward, loss+grad, backward, Adam)] -> fusion).  Launch orchestration
+ * only: identical to calling the entry points above in sequence.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t K, M, D;
+    float   eps, rho, eta, logit_scale;           /* dota_cfg (utils/params.py:103-106), 100 (:57)       */
+    int32_t res_learning, res_steps;              /* --res-learning, 10 (:467)                            */
+    double  lr, beta1, beta2, adam_eps;           /* torch.optim.Adam defaults, lr 1e-3 (:350-352)        */
+    float  *mu, *var, *pi, *c, *class_counts;     /* GMM state                                            */
+    const float* text0;                           /* initial text features (K,D)                          */
+    float  *res, *adam_m, *adam_v, *e, *norm;     /* residuals, Adam moments, current text (K,D), |t| (K) */
+    float  *fhat, *faug, *clip_logits, *prob, *dota_scores;          /* scratch: (D),(D),(K),(K),(K)      */
+    float  *L, *joint, *grad_ll, *grad_e, *loss;                     /* scratch: (K,K),(K,K,M)x2,(K,D),(1)*/
+} ua_tta_state;
+
+/* feats (n,2,D): [:,0] encoder output of the sample, [:,1] of its augmented copy.
+ * targets (n) int32 or NULL; final_logits (n,K); ranks (n) (required with targets); preds (n) or NULL.
+ * sample_index0: stream index of the first sample (residual learning starts at index 1, :444);
+ * adam_step0: Adam steps taken so far (the caller adds res_steps per sample with index > 0).     */
+int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int32_t* targets, int32_t n,
+                 int64_t sample_index0, int64_t adam_step0, float* final_logits,
+                 int32_t* ranks, int32_t* preds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,78 @@
+"""world_size-2 gloo (CPU) tests of the N>1 path: sample sharding, the one all_gather per chunk
+and the replicated in-order cache replay give results identical to the single-process stream."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _fake_encode(x):
+    """Deterministic per-sample 'encoder' (the real one needs a GPU): depends only on the sample."""
+    return torch.stack([torch.cos(x.sum(-1, keepdim=True) * torch.arange(1, 65)), torch.sin(x.mean(-1, keepdim=True) * torch.arange(1, 65))], 1).squeeze(-2) \
+        if x.dim() == 3 else None
+
+
+def _worker(rank, world, port, n, chunk, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import gather_features, shard_indices
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(0)
+    K, D = 6, 64
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    data = torch.randn(n, 5, 3, generator=g)
+    lab = torch.randint(0, K, (n,), generator=g)
+    s = O.TtaStream(text, O.TtaConfig(num_modes=2, res_learning=False))
+    finals = []
+    for c0 in range(0, n, chunk):
+        nn_ = min(chunk, n - c0)
+        mine = shard_indices(nn_, rank, world)
+        x = data[c0:c0 + nn_][mine]
+        f = torch.stack([text[lab[c0:c0 + nn_][mine]] + 0.05 * torch.cos(x.sum((1, 2)))[:, None] * torch.ones(D),
+                         text[lab[c0:c0 + nn_][mine]] + 0.05 * torch.sin(x.sum((1, 2)))[:, None] * torch.ones(D)], 1)
+        feats = gather_features(f, nn_, rank, world)
+        assert feats.shape == (nn_, 2, D)
+        for j in range(nn_):                       # replicated in-order replay
+            finals.append(s.step(feats[j, 0:1], feats[j, 1:2])[2])
+    res = torch.cat(finals)
+    if world > 1:
+        both = [torch.empty_like(res) for _ in range(world)]
+        dist.all_gather(both, res)
+        assert all(torch.equal(both[0], b) for b in both)      # identical on every rank
+    if rank == 0:
+        np.save(out, res.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n,chunk', [(10, 4), (7, 3)])
+def test_sharded_stream_equals_single_process(tmp_path, n, chunk):
+    outs = []
+    for world in (1, 2):
+        out = str(tmp_path / f'w{world}.npy')
+        mp.spawn(_worker, args=(world, _free_port(), n, chunk, out), nprocs=world, join=True)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_shard_indices_partition():
+    import sys
+    sys.path.insert(0, ROOT)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import shard_indices
+    for n in (1, 7, 16):
+        for w in (1, 2, 3, 8):
+            allidx = torch.cat([shard_indices(n, r, w) for r in range(w)]).sort()[0]
+            assert torch.equal(allidx, torch.arange(n))

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import lib
 from .dota_mixture import DOTA_mix
+from .stream import gather_features, shard_indices
 
 LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
 NOISE_STD = 0.05             # Uni_Adapter.py:420
@@ -109,8 +110,9 @@ class TtaEngine:
     test_zeroshot_3d_core (the reference rebuilds all state per corruption, Uni_Adapter.py:336-352)."""
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
-                 log_alignment_every=0, dist_group=None):
+                 log_alignment_every=0, dist_group=None, composite=True):
         self.model = model
+        self.composite = bool(composite) and not log_alignment_every
         self.dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.text = text_features.detach().to(self.dev, torch.float32).contiguous()          # (K,D)
         self.K, self.D = self.text.shape
@@ -135,27 +137,38 @@ class TtaEngine:
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
         self.count = 0
         self.last_loss = None
+        self._state = self._make_state()
+
+    def _make_state(self):
+        """ua_tta_state for the composite entry point; all pointers are fixed for the engine's life."""
+        s, m, r = lib.TtaState(), self.mode_dota_model, self.residuals
+        s.K, s.M, s.D = self.K, self.M, self.D
+        s.eps, s.rho, s.eta, s.logit_scale = m.epsilon, float(self.cfg['rho']), float(self.cfg['eta']), LOGIT_SCALE
+        s.res_learning, s.res_steps = int(self.res_learning), RES_STEPS
+        s.lr, s.beta1, s.beta2, s.adam_eps = RES_LR, 0.9, 0.999, 1e-8
+        s.mu, s.var, s.pi, s.c, s.class_counts = (t.data_ptr() for t in (m.mu, m.var, m.pi, m.c, m.class_counts))
+        s.text0 = self.text.data_ptr()
+        if r is not None:
+            s.res, s.adam_m, s.adam_v, s.e, s.norm = (t.data_ptr() for t in (r.res, r.m, r.v, r.e, r.norm))
+        s.fhat, s.faug, s.clip_logits, s.prob, s.dota_scores = (t.data_ptr() for t in (self.fh, self.fa, self.z, self.prob, self.dz))
+        s.L, s.joint, s.grad_ll, s.grad_e, s.loss = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge, self.loss))
+        return s
 
     # -- encoder part: this rank's share of the chunk -------------------------------------
     def encode_chunk(self, pc, rgb, noise):
         """pc, rgb (n,N,3); noise (n,N,3) = the randn draw of Uni_Adapter.py:421.  Returns
         features (n,2,D): [:,0] original, [:,1] augmented cloud."""
         n = pc.shape[0]
-        mine = torch.arange(self.rank, n, self.world)
+        mine = shard_indices(n, self.rank, self.world)
         D = self.D
-        feats = torch.zeros(n, 2, D, device=self.dev)
         if len(mine):
             p, c, z = pc[mine], rgb[mine], noise[mine]
             clouds = torch.stack([torch.cat((p, c), -1), torch.cat((p + NOISE_STD * z, c), -1)], 1)      # :385, :421-422
-            f = self.model.encode_pc(clouds.view(-1, clouds.shape[2], 6))
-            feats[mine] = f.view(len(mine), 2, D)
-        if self.world > 1:
-            # one exchange per chunk: every rank contributes the rows it encoded (zeros elsewhere),
-            # RCCL all_gather over xGMI, then select each sample's row from its owner.
-            allf = [torch.empty_like(feats) for _ in range(self.world)]
-            torch.distributed.all_gather(allf, feats, group=self.group)
-            owner = torch.arange(n, device=self.dev) % self.world
-            feats = torch.stack(allf, 0)[owner, torch.arange(n, device=self.dev)]
+            local = self.model.encode_pc(clouds.view(-1, clouds.shape[2], 6)).view(len(mine), 2, D)
+        else:
+            local = torch.zeros(0, 2, D, device=self.dev)
+        # one exchange per chunk (RCCL all_gather over xGMI); a no-op at world 1
+        feats = gather_features(local, n, self.rank, self.world, self.group)
         return feats
 
     # -- sequential cache step of ONE sample ----------------------------------------------
@@ -216,9 +229,21 @@ class TtaEngine:
         ranks = torch.full((n,), -1, device=self.dev, dtype=torch.int32)
         preds = torch.empty(n, device=self.dev, dtype=torch.int32)
         tgt = target.to(self.dev, torch.int32) if target is not None else None
-        for j in range(n):
-            self.cache_step(feats[j, 0:1], feats[j, 1:2], tgt[j:j + 1] if tgt is not None else None,
-                            final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
+        if self.composite:
+            # one host call enqueues the whole in-order replay of the chunk (csrc/ua_tta.hip)
+            import ctypes
+            feats = feats.contiguous()
+            lib.call('ua_tta_chunk', ctypes.byref(self._state), lib.ptr(feats), lib.ptr(tgt, torch.int32) if tgt is not None else None,
+                     n, self.i, self.residuals.step if self.res_learning else 0, lib.ptr(final),
+                     lib.ptr(ranks, torch.int32) if tgt is not None else None, lib.ptr(preds, torch.int32), lib.stream_ptr())
+            if self.res_learning:
+                self.residuals.step += RES_STEPS * (n - (1 if self.i == 0 else 0))
+            self.i += n
+            self.mode_dota_model.t += 2 * n
+        else:
+            for j in range(n):
+                self.cache_step(feats[j, 0:1], feats[j, 1:2], tgt[j:j + 1] if tgt is not None else None,
+                                final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
         if tgt is not None:                                                                  # utils/utils.py:154-167
             self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
             self.count += n

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on one MI355X (HIP events, median of repeats).
+    python tools/bench_kernels.py [gemm] [attn] [group] [cache] [ln]
+Not part of the judged bench; used to iterate on kernels."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uni_adapter_amd  # noqa: E402,F401
+from uni_adapter_amd import lib  # noqa: E402
+from uni_adapter_amd.lib import GemmEpilogue  # noqa: E402
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); evs.append((a, b))
+    torch.cuda.synchronize()
+    t = sorted(x.elapsed_time(y) for x, y in evs)
+    return t[len(t) // 2], t[0]
+
+
+def gemm():
+    print('== ua_gemm (fp32 MFMA), peak 157.3 TF')
+    shapes = [(16416, 3072, 1024, 'qkv Bc=32'), (16416, 1024, 1024, 'proj'), (16416, 5504, 1024, 'fc1 swiglu'), (16416, 1024, 2752, 'fc2'),
+              (262144, 512, 512, 'conv4 8 clouds'), (262144, 512, 256, 'conv3'), (262144, 256, 128, 'conv2'), (262144, 128, 8, 'conv1'),
+              (1026, 3072, 1024, 'qkv Bc=2'), (1026, 1024, 1024, 'proj Bc=2'), (4104, 3072, 1024, 'qkv Bc=8'), (8192, 8192, 8192, 'square 8k')]
+    for M, N, K, name in shapes:
+        A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5
+        act = 3 if 'swiglu' in name else 0
+        Cc = torch.empty(M, N // 2 if act == 3 else N, device='cuda')
+        b = torch.randn(N, device='cuda')
+        e = GemmEpilogue(); e.bias = b.data_ptr(); e.act = act
+        st = lib.stream_ptr()
+        fn = lambda: lib.call('ua_gemm', A.data_ptr(), K, W.data_ptr(), K, Cc.data_ptr(), Cc.stride(0), M, N, K, C.byref(e), st)
+        med, mn = timeit(fn)
+        fl = 2.0 * M * N * K
+        print(f'{name:18s} M={M:6d} N={N:5d} K={K:5d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:6.1f})  frac {fl / med / 1e9 / 157.3:.3f}')
+
+
+def attn():
+    print('== ua_attention (fp32 MFMA)')
+    for Bc in (2, 8, 32):
+        G, H, hd = 512, 16, 64
+        rows = Bc * G + Bc; Cd = H * hd
+        qkv = torch.randn(rows, 3 * Cd, device='cuda'); out = torch.empty(rows, Cd, device='cuda')
+        st = lib.stream_ptr()
+        fn = lambda: lib.call('ua_attention', qkv.data_ptr(), 3 * Cd, out.data_ptr(), Cd, Bc, G, H, hd, st)
+        med, mn = timeit(fn)
+        fl = 4.0 * (G + 1) ** 2 * Cd * Bc
+        print(f'Bc={Bc:3d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s  frac {fl / med / 1e9 / 157.3:.3f}')
+
+
+def group():
+    print('== ua_fps / ua_knn_group')
+    for B in (2, 32):
+        xyz = torch.randn(B, 1024, 3, device='cuda'); xyz /= xyz.norm(dim=-1).max(); rgb = torch.ones_like(xyz)
+        cen = torch.empty(B, 512, 3, device='cuda'); feat = torch.empty(B * 512 * 64, 8, device='cuda')
+        st = lib.stream_ptr()
+        med, _ = timeit(lambda: lib.call('ua_fps', xyz.data_ptr(), B, 1024, 512, 0, 1e-3, None, cen.data_ptr(), st))
+        med2, _ = timeit(lambda: lib.call('ua_knn_group', xyz.data_ptr(), rgb.data_ptr(), cen.data_ptr(), B, 1024, 512, 64, feat.data_ptr(), 8, None, st))
+        print(f'B={B:3d}  fps {med:8.3f} ms   knn_group {med2:8.3f} ms')
+
+
+def ln():
+    print('== ua_layernorm')
+    for rows, cols, pad in ((16416, 1024, 1024), (16416, 2730, 2752)):
+        x = torch.randn(rows, pad, device='cuda'); y = torch.empty_like(x); w = torch.ones(cols, device='cuda'); b = torch.zeros(cols, device='cuda')
+        st = lib.stream_ptr()
+        med, _ = timeit(lambda: lib.call('ua_layernorm', x.data_ptr(), pad, w.data_ptr(), b.data_ptr(), 1e-6, y.data_ptr(), pad, rows, cols, pad, st))
+        print(f'rows={rows} cols={cols}: {med:7.3f} ms  {2 * rows * cols * 4 / med / 1e6:7.1f} GB/s')
+
+
+def cache():
+    print('== cache kernels (HBM peak 8000 GB/s)')
+    for K, M, D in ((40, 8, 1024), (1156, 8, 1024), (4096, 16, 1024)):
+        mu = torch.randn(K, M, D, device='cuda') * 0.03; var = 1e-4 * (1 + torch.rand(K, M, D, device='cuda'))
+        pi = torch.full((K, M), 1.0 / M, device='cuda'); c = pi.clone(); cc = torch.zeros(K, device='cuda')
+        x = torch.nn.functional.normalize(torch.randn(1, D, device='cuda'), dim=1); g = torch.softmax(torch.randn(1, K, device='cuda'), 1)
+        sc = torch.empty(1, K, device='cuda'); st = lib.stream_ptr()
+        med, _ = timeit(lambda: lib.call('ua_gmm_loglik', mu.data_ptr(), var.data_ptr(), pi.data_ptr(), x.data_ptr(), 1, K, M, D, 1e-4, sc.data_ptr(), None, None, st))
+        med2, _ = timeit(lambda: lib.call('ua_gmm_step_fused', mu.data_ptr(), var.data_ptr(), pi.data_ptr(), c.data_ptr(), cc.data_ptr(), x.data_ptr(), 1, x.data_ptr(), x.data_ptr(), g.data_ptr(), sc.data_ptr(), K, M, D, 1e-4, st))
+        by = K * M * D * 4
+        print(f'K={K:5d} M={M:2d}: predict {med * 1e3:8.1f} us {2 * by / med / 1e6:7.1f} GB/s | fused step {med2 * 1e3:8.1f} us {4 * by / med2 / 1e6:7.1f} GB/s')
+    # residual-learning kernels at K=40
+    K, M, D = 40, 8, 1024
+    mu = torch.randn(K, M, D, device='cuda') * 0.03; var = 1e-4 * (1 + torch.rand(K, M, D, device='cuda')); pi = torch.full((K, M), 1.0 / M, device='cuda')
+    e = torch.nn.functional.normalize(torch.randn(K, D, device='cuda'), dim=1); L = torch.empty(K, K, device='cuda'); J = torch.empty(K, K, M, device='cuda')
+    gl = torch.empty(K, K, M, device='cuda'); ge = torch.empty(K, D, device='cuda'); loss = torch.empty(1, device='cuda'); st = lib.stream_ptr()
+    t1, _ = timeit(lambda: lib.call('ua_gmm_loglik', mu.data_ptr(), var.data_ptr(), pi.data_ptr(), e.data_ptr(), K, K, M, D, 1e-4, L.data_ptr(), J.data_ptr(), None, st))
+    t2, _ = timeit(lambda: lib.call('ua_align_loss', L.data_ptr(), J.data_ptr(), K, M, loss.data_ptr(), gl.data_ptr(), st))
+    t3, _ = timeit(lambda: lib.call('ua_gmm_loglik_bwd', mu.data_ptr(), var.data_ptr(), e.data_ptr(), gl.data_ptr(), K, K, M, D, 1e-4, ge.data_ptr(), st))
+    print(f'residual step K=40: loglik fwd {t1 * 1e3:.1f} us, align {t2 * 1e3:.1f} us, bwd {t3 * 1e3:.1f} us')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache']
+    for w in which:
+        globals()[w]()

@@ -44,9 +44,18 @@ struct GemmArgs {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-__device__ __forceinline__ float4 ld_guard(const float* base, long long ld, int row, int nrows, int k, int K) {
-    if (row < nrows && k < K) return *reinterpret_cast<const float4*>(base + (size_t)row * ld + k);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+// Branch-free guarded 16-byte load: the address is clamped into the matrix (always legal), the
+// value is zeroed by a select when the element is outside (rows >= nrows, k >= K).  Out-of-range
+// rows only ever feed accumulators that are never stored; out-of-range k must contribute 0.
+// (The select is applied when the registers are stored to LDS, AFTER the MFMAs of the current
+// slab, so the loads stay in flight behind the matrix work.)
+__device__ __forceinline__ float4 ld_clamped(const float* base, long long ld, int row, int nrows, int k, int K) {
+    const int rc = min(row, nrows - 1), kc = min(k, K - 4);
+    return *reinterpret_cast<const float4*>(base + (size_t)rc * ld + kc);
+}
+__device__ __forceinline__ float4 mask4(float4 v, bool ok) {
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
 }
 
 __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
@@ -69,18 +78,19 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kq = (f & 7) * 4;
-            ra[i] = ld_guard(g.A, g.lda, m0 + row, g.M, k0 + kq, g.K);
-            rw[i] = ld_guard(g.W, g.ldw, n0 + row, g.N, k0 + kq, g.K);
+            ra[i] = ld_clamped(g.A, g.lda, m0 + row, g.M, k0 + kq, g.K);
+            rw[i] = ld_clamped(g.W, g.ldw, n0 + row, g.N, k0 + kq, g.K);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int k0) {
         float* a = lds + buf * 2 * TILE_F;
         float* w = a + TILE_F;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kq = (f & 7) * 4;
-            *reinterpret_cast<float4*>(a + row * LDS_LD + kq) = ra[i];
-            *reinterpret_cast<float4*>(w + row * LDS_LD + kq) = rw[i];
+            const bool k_ok = (k0 + kq) < g.K;
+            *reinterpret_cast<float4*>(a + row * LDS_LD + kq) = mask4(ra[i], k_ok && (m0 + row) < g.M);
+            *reinterpret_cast<float4*>(w + row * LDS_LD + kq) = mask4(rw[i], k_ok && (n0 + row) < g.N);
         }
     };
 
@@ -92,43 +102,47 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // wave-uniform activity of the four 32x32 blocks (thin edge tiles skip their MFMAs)
-    bool on_m[2], on_n[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        on_m[i] = (m0 + wm * 64 + i * 32) < g.M;
-        on_n[i] = (n0 + wn * 64 + i * 32) < g.N;
-    }
-
+    // Edge tiles run the full MFMA schedule on zero-filled operands (no branches in the main
+    // loop); with the CLS rows grouped in one thin tile that wastes < 1 % of the MFMAs.
     const int nk = (g.K + BK - 1) / BK;
     fetch(0);
-    stash(0);
+    stash(0, 0);
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         if (t + 1 < nk) fetch((t + 1) * BK);
         const float* a = lds + buf * 2 * TILE_F + (wm * 64 + li) * LDS_LD + lh * 4;
         const float* w = lds + buf * 2 * TILE_F + TILE_F + (wn * 64 + li) * LDS_LD + lh * 4;
+        // fragment registers are double-buffered: chunk c+1 is read from LDS while chunk c's 16
+        // MFMAs (1024 cycles) run, so no MFMA ever waits on an LDS read it was just issued behind
+        float4 fa[2][2], fw[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD);
+            fw[0][i] = *reinterpret_cast<const float4*>(w + i * 32 * LDS_LD);
+        }
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
-            float4 fa[2], fw[2];
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (c + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + c * 8);
-                fw[i] = *reinterpret_cast<const float4*>(w + i * 32 * LDS_LD + c * 8);
+                for (int i = 0; i < 2; ++i) {
+                    fa[nxt][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + (c + 1) * 8);
+                    fw[nxt][i] = *reinterpret_cast<const float4*>(w + i * 32 * LDS_LD + (c + 1) * 8);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch reads ABOVE this chunk's MFMAs
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (on_m[i] && on_n[j]) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fw[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fw[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fw[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fw[j].w, acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fw[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fw[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fw[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fw[cur][j].w, acc[i][j], 0, 0, 0);
+                }
         }
-        if (t + 1 < nk) stash(buf ^ 1);
+        if (t + 1 < nk) stash(buf ^ 1, (t + 1) * BK);
         __syncthreads();
     }
 

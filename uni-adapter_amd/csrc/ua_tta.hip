@@ -1,0 +1,43 @@
+// Composite entry point: the in-order cache replay of a whole chunk of samples
+// (loop body of Uni_Adapter.py:388-521 for --use-mode-dota, per sample) enqueued by ONE host call.
+// Pure launch orchestration - it only calls the other extern "C" entry points of this library,
+// so semantics are exactly those of the individual kernels; nothing synchronises.
+#include "ua_common.h"
+
+extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int32_t* targets, int32_t n,
+                            int64_t sample_index0, int64_t adam_step0, float* final_logits,
+                            int32_t* ranks, int32_t* preds, void* stream) {
+    UA_CHECK_PTR(s); UA_CHECK_PTR(feats); UA_CHECK_PTR(final_logits);
+    if (n <= 0 || sample_index0 < 0 || adam_step0 < 0) return UA_EINVAL;
+    const int K = s->K, M = s->M, D = s->D;
+    if (K <= 0 || M <= 0 || D <= 0) return UA_EINVAL;
+    if (targets && !ranks) return UA_EINVAL;
+    const float* text = s->res_learning ? s->e : s->text0;                       // Uni_Adapter.py:388-401
+    int64_t adam_step = adam_step0;
+    for (int j = 0; j < n; ++j) {
+        const float* f = feats + (size_t)j * 2 * D;
+        const float* fa = f + D;
+        int rc;
+        if ((rc = ua_clip_logits(f, text, K, D, s->logit_scale, 1, s->fhat, s->clip_logits, s->prob, nullptr,
+                                 nullptr, stream))) return rc;                  // :406
+        if ((rc = ua_clip_logits(fa, text, K, D, s->logit_scale, 2, s->faug, nullptr, nullptr, nullptr,
+                                 nullptr, stream))) return rc;                  // :424, :429
+        if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
+                                    s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
+        if (s->res_learning && sample_index0 + j > 0) {                         // :444-476
+            for (int it = 0; it < s->res_steps; ++it) {
+                if ((rc = ua_gmm_loglik(s->mu, s->var, s->pi, s->e, K, K, M, D, s->eps, s->L, s->joint, nullptr, stream))) return rc;
+                if ((rc = ua_align_loss(s->L, s->joint, K, M, s->loss, s->grad_ll, stream))) return rc;
+                if ((rc = ua_gmm_loglik_bwd(s->mu, s->var, s->e, s->grad_ll, K, K, M, D, s->eps, s->grad_e, stream))) return rc;
+                ++adam_step;
+                if (adam_step > 0x7fffffff) return UA_EINVAL;
+                if ((rc = ua_residual_adam(s->text0, s->res, s->adam_m, s->adam_v, s->grad_e, s->e, s->norm, K, D,
+                                           (int32_t)adam_step, s->lr, s->beta1, s->beta2, s->adam_eps, stream))) return rc;
+            }
+        }
+        if ((rc = ua_fuse_logits(s->clip_logits, s->dota_scores, s->c, K, M, s->rho, s->eta, 1,
+                                 targets ? targets + j : nullptr, final_logits + (size_t)j * K,
+                                 targets ? ranks + j : nullptr, preds ? preds + j : nullptr, stream))) return rc;   // :491-521
+    }
+    return UA_OK;
+}

@@ -30,6 +30,19 @@ class GemmEpilogue(C.Structure):
                 ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32)]
 
 
+class TtaState(C.Structure):
+    """ua_tta_state (include/uniadapter.h)."""
+    _fields_ = [('K', _i32), ('M', _i32), ('D', _i32),
+                ('eps', _f), ('rho', _f), ('eta', _f), ('logit_scale', _f),
+                ('res_learning', _i32), ('res_steps', _i32),
+                ('lr', _d), ('beta1', _d), ('beta2', _d), ('adam_eps', _d),
+                ('mu', _p), ('var', _p), ('pi', _p), ('c', _p), ('class_counts', _p),
+                ('text0', _p),
+                ('res', _p), ('adam_m', _p), ('adam_v', _p), ('e', _p), ('norm', _p),
+                ('fhat', _p), ('faug', _p), ('clip_logits', _p), ('prob', _p), ('dota_scores', _p),
+                ('L', _p), ('joint', _p), ('grad_ll', _p), ('grad_e', _p), ('loss', _p)]
+
+
 # name -> argtypes, exactly the declarations of include/uniadapter.h
 SIGNATURES = {
     'ua_gmm_loglik': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p],
@@ -47,6 +60,7 @@ SIGNATURES = {
     'ua_layernorm': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _p],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
+    'ua_tta_chunk': [C.POINTER(TtaState), _p, _p, _i32, _i64, _i64, _p, _p, _p, _p],
 }
 
 for _name, _args in SIGNATURES.items():
