@@ -113,6 +113,18 @@ int ua_text_normalize(const float* text0, const float* res, int32_t K, int32_t D
 int ua_align_loss(const float* L, const float* joint, int32_t K, int32_t M,
                   float* loss_out, float* grad_ll, void* stream);
 
+/* Fast path of the alignment forward/backward.  The GMM state is constant during the res_steps Adam
+ * steps of one sample, so 1/max(var+eps,1e-8) (K,M,D) and row_const[k,m] = ln(pi+1e-10) - 1/2 sum_d
+ * ln v (K,M) are prepared once per sample; forward then is joint = row_const - 1/2 sum (e-mu)^2*inv_var
+ * and L = logsumexp_m joint (same quantities as ua_gmm_loglik with B = K queries, Uni_Adapter.py:219-244),
+ * backward is grad_e = sum_{k,m} grad_ll (mu - e)*inv_var (same as ua_gmm_loglik_bwd).            */
+int ua_gmm_prepare_alignment(const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
+                             float* inv_var, float* row_const, void* stream);
+int ua_align_forward(const float* mu, const float* inv_var, const float* row_const, const float* e,
+                     int32_t B, int32_t K, int32_t M, int32_t D, float* L, float* joint, void* stream);
+int ua_align_backward(const float* mu, const float* inv_var, const float* e, const float* grad_ll,
+                      int32_t B, int32_t K, int32_t M, int32_t D, float* grad_e, void* stream);
+
 /* Chain grad_e through e = t/|t| (t = text0+res), apply one torch.optim.Adam step
  * (lr, betas, eps as Uni_Adapter.py:350-352; `step` is the 1-based step count) to res and its
  * moments, then refresh e and norm for the next evaluation.  All (K,D) except norm (K).        */
@@ -197,6 +209,7 @@ typedef struct {
     float  *res, *adam_m, *adam_v, *e, *norm;     /* residuals, Adam moments, current text (K,D), |t| (K) */
     float  *fhat, *faug, *clip_logits, *prob, *dota_scores;          /* scratch: (D),(D),(K),(K),(K)      */
     float  *L, *joint, *grad_ll, *grad_e, *loss;                     /* scratch: (K,K),(K,K,M)x2,(K,D),(1)*/
+    float  *inv_var, *row_const;                                     /* scratch: (K,M,D),(K,M)            */
 } ua_tta_state;
 
 /* feats (n,2,D): [:,0] encoder output of the sample, [:,1] of its augmented copy.

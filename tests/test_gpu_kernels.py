@@ -416,3 +416,31 @@ def test_attention(ua, Bc, G, H):
         q, k, v = [t.reshape(G + 1, H, hd).transpose(0, 1) for t in x.split(C, -1)]
         ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(0, 1).reshape(G + 1, C)
         assert (o[r] - ref).abs().max().item() < 2e-5
+
+
+def test_alignment_fast_path_equals_generic_kernels(ua, golden_dir):
+    """ua_gmm_prepare_alignment + ua_align_forward/backward (1/v and row constants hoisted out of
+    the 10-step loop) against the generic ua_gmm_loglik / ua_gmm_loglik_bwd and the fp64 oracle."""
+    g = _load(golden_dir, 'g3_alignment_scanobjectnn.npz')
+    K, M = g['pi'].shape; D = g['mu'].shape[2]; eps = float(g['eps'])
+    mu, var, pi = dev(_t(g['mu'])), dev(_t(g['var'])), dev(_t(g['pi']))
+    t = _t(g['text']) + _t(g['res']); e = dev(t / t.norm(dim=1, keepdim=True))
+    iv = torch.empty(K, M, D, device='cuda'); rc = torch.empty(K, M, device='cuda')
+    ua.call('ua_gmm_prepare_alignment', ua.ptr(var), ua.ptr(pi), K, M, D, eps, ua.ptr(iv), ua.ptr(rc), ua.stream_ptr())
+    L1 = torch.empty(K, K, device='cuda'); J1 = torch.empty(K, K, M, device='cuda')
+    ua.call('ua_align_forward', ua.ptr(mu), ua.ptr(iv), ua.ptr(rc), ua.ptr(e), K, K, M, D, ua.ptr(L1), ua.ptr(J1), ua.stream_ptr())
+    L0 = torch.empty(K, K, device='cuda'); J0 = torch.empty(K, K, M, device='cuda')
+    ua.call('ua_gmm_loglik', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(e), K, K, M, D, eps, ua.ptr(L0), ua.ptr(J0), None, ua.stream_ptr())
+    st = O.GmmState(_t(g['mu']).double(), _t(g['var']).double(), _t(g['pi']).double(), _t(g['c']).double(), torch.zeros(K).double(), eps)
+    J64 = O.gmm_joint(st, e.cpu().double())
+    assert (J1.cpu().double() - J64).abs().max().item() <= 2e-3
+    assert (J1 - J0).abs().max().item() <= 2e-3 and (L1 - L0).abs().max().item() <= 2e-3
+    w = torch.randn(K, K, M, generator=torch.Generator().manual_seed(0)); wd = dev(w)
+    g1 = torch.empty(K, D, device='cuda'); g0 = torch.empty(K, D, device='cuda')
+    ua.call('ua_align_backward', ua.ptr(mu), ua.ptr(iv), ua.ptr(e), ua.ptr(wd), K, K, M, D, ua.ptr(g1), ua.stream_ptr())
+    ua.call('ua_gmm_loglik_bwd', ua.ptr(mu), ua.ptr(var), ua.ptr(e), ua.ptr(wd), K, K, M, D, eps, ua.ptr(g0), ua.stream_ptr())
+    ex = e.cpu().double().requires_grad_(True)
+    (O.gmm_log_likelihood(ex, st.mu, O.gmm_get_var(st)) * w.double()).sum().backward()
+    ref = ex.grad
+    assert (g1.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert (g0.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()

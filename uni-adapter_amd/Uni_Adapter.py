@@ -134,6 +134,7 @@ class TtaEngine:
         self.fh, self.fa = e(1, D), e(1, D)
         self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
         self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
+        self.inv_var, self.row_const = e(K, M, D), e(K, M)
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
         self.count = 0
         self.last_loss = None
@@ -152,6 +153,7 @@ class TtaEngine:
             s.res, s.adam_m, s.adam_v, s.e, s.norm = (t.data_ptr() for t in (r.res, r.m, r.v, r.e, r.norm))
         s.fhat, s.faug, s.clip_logits, s.prob, s.dota_scores = (t.data_ptr() for t in (self.fh, self.fa, self.z, self.prob, self.dz))
         s.L, s.joint, s.grad_ll, s.grad_e, s.loss = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge, self.loss))
+        s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
         return s
 
     # -- encoder part: this rank's share of the chunk -------------------------------------
@@ -186,6 +188,8 @@ class TtaEngine:
         mdl.step_fused(self.fh, self.fh, self.fa, self.prob, scores=self.dz)                 # :416,:417,:430
         if self.i > 0 and self.res_learning:                                                 # :444-476
             r = self.residuals
+            lib.call('ua_gmm_prepare_alignment', lib.ptr(mdl.var), lib.ptr(mdl.pi), K, M, D, mdl.epsilon, lib.ptr(self.inv_var),
+                     lib.ptr(self.row_const), st)
             for _ in range(RES_STEPS):
                 self._align_eval(r, with_grad=True)
                 r.step += 1
@@ -204,13 +208,13 @@ class TtaEngine:
         K, M, D = self.K, self.M, self.D
         mdl = self.mode_dota_model
         st = lib.stream_ptr()
-        lib.call('ua_gmm_loglik', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(mdl.pi), lib.ptr(r.e), K, K, M, D, mdl.epsilon,
-                 lib.ptr(self.L), lib.ptr(self.joint), None, st)
+        lib.call('ua_align_forward', lib.ptr(mdl.mu), lib.ptr(self.inv_var), lib.ptr(self.row_const), lib.ptr(r.e), K, K, M, D,
+                 lib.ptr(self.L), lib.ptr(self.joint), st)
         lib.call('ua_align_loss', lib.ptr(self.L), lib.ptr(self.joint), K, M, lib.ptr(self.loss),
                  lib.ptr(self.gll) if with_grad else None, st)
         if with_grad:
-            lib.call('ua_gmm_loglik_bwd', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(r.e), lib.ptr(self.gll), K, K, M, D,
-                     mdl.epsilon, lib.ptr(self.ge), st)
+            lib.call('ua_align_backward', lib.ptr(mdl.mu), lib.ptr(self.inv_var), lib.ptr(r.e), lib.ptr(self.gll), K, K, M, D,
+                     lib.ptr(self.ge), st)
 
     # -- one chunk ---------------------------------------------------------------------------
     @torch.no_grad()

@@ -58,20 +58,12 @@ __device__ __forceinline__ float4 mask4(float4 v, bool ok) {
     return v;
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
+// K loop of one workgroup.  FULL = interior tile: branch-free.  !FULL = edge tile: 32x32 MFMA
+// blocks that lie completely outside the matrix are skipped (scalar predicates `on`).
+template <bool FULL>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, int m0, int n0, int tid, int wm, int wn,
+                                              int li, int lh, const bool (&on)[2][2], f32x16 (&acc)[2][2]) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [2 buffers][A tile | W tile]
-    // ---- XCD-aware tile id (bijective for any n_tiles) ----
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = g.n_tiles >> 3, r = g.n_tiles & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
-
     // staging map: 4 float4 per thread per operand; f = tid + 256*i -> row f/8, k-quad f%8
     float4 ra[4], rw[4];
     auto fetch = [&](int k0) {
@@ -93,28 +85,17 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
             *reinterpret_cast<float4*>(w + row * LDS_LD + kq) = mask4(rw[i], k_ok && (n0 + row) < g.N);
         }
     };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // Edge tiles run the full MFMA schedule on zero-filled operands (no branches in the main
-    // loop); with the CLS rows grouped in one thin tile that wastes < 1 % of the MFMAs.
     const int nk = (g.K + BK - 1) / BK;
     fetch(0);
     stash(0, 0);
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nk) fetch((t + 1) * BK);
+        fetch((t + 1) * BK);        // unconditional (addresses are clamped): keeps the loop body straight-line
         const float* a = lds + buf * 2 * TILE_F + (wm * 64 + li) * LDS_LD + lh * 4;
         const float* w = lds + buf * 2 * TILE_F + TILE_F + (wn * 64 + li) * LDS_LD + lh * 4;
         // fragment registers are double-buffered: chunk c+1 is read from LDS while chunk c's 16
-        // MFMAs (1024 cycles) run, so no MFMA ever waits on an LDS read it was just issued behind
+        // MFMAs (1024 cycles) run, so no MFMA waits on an LDS read it was just issued behind
         float4 fa[2][2], fw[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -135,16 +116,54 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fw[cur][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fw[cur][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fw[cur][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fw[cur][j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j)
+                    if (FULL || on[i][j]) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fw[cur][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fw[cur][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fw[cur][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fw[cur][j].w, acc[i][j], 0, 0, 0);
+                    }
         }
-        if (t + 1 < nk) stash(buf ^ 1, (t + 1) * BK);
+        stash(buf ^ 1, (t + 1) * BK);   // past the last slab this stores zeros nobody reads
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
+    // ---- XCD-aware tile id (bijective for any n_tiles) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = g.n_tiles >> 3, r = g.n_tiles & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Interior tiles (block-uniform test on kernel arguments) take the branch-free main loop.  Edge
+    // tiles - here the thin tile that holds the CLS rows and the last column tile of the 2730-wide
+    // layers - skip the MFMA blocks outside the matrix; the predicates are made scalar with
+    // readfirstlane so the skip is an s_cbranch, not an exec mask.
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    const int swm = __builtin_amdgcn_readfirstlane(wm), swn = __builtin_amdgcn_readfirstlane(wn);
+    bool on[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            on[i][j] = ((m0 + swm * 64 + i * 32) < g.M) && ((n0 + swn * 64 + j * 32) < g.N);
+    if (full) gemm_mainloop<true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+    else      gemm_mainloop<false>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
 
     // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = li (within the 32x32) ----
     const bool swiglu = g.act == 3;

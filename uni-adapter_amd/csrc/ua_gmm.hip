@@ -254,6 +254,111 @@ gmm_loglik_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ va
     gx[(size_t)b * D + d] = (float)acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// Residual-learning fast path (Uni_Adapter.py:444-476).  The GMM state does not change during the
+// 10 Adam steps of a sample, so 1/v and the per-row constant ln(pi+1e-10) - 1/2 sum ln v are
+// computed ONCE per sample (gmm_prepare_kernel) and the 11 forward / 10 backward evaluations are
+// pure multiply-add streams over L2-resident rows.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(1024)
+gmm_prepare_kernel(const float* __restrict__ var, const float* __restrict__ pi, int M, float eps,
+                   float* __restrict__ inv_var, float* __restrict__ row_const) {
+    constexpr int D = 256 * VEC;
+    const int k = blockIdx.x, m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t off = ((size_t)k * M + m) * D;
+    const float4* pv = reinterpret_cast<const float4*>(var + off);
+    float4* po = reinterpret_cast<float4*>(inv_var + off);
+    double acc = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float4 a = pv[v * 64 + lane];
+        const float x = reg_var(a.x, eps), y = reg_var(a.y, eps), z = reg_var(a.z, eps), w = reg_var(a.w, eps);
+        acc += (double)logf(x) + (double)logf(y) + (double)logf(z) + (double)logf(w);
+        po[v * 64 + lane] = make_float4(1.0f / x, 1.0f / y, 1.0f / z, 1.0f / w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) row_const[k * M + m] = (float)((double)logf(pi[k * M + m] + 1e-10f) - 0.5 * acc);
+}
+
+constexpr int kAlignQ = 4;      // queries per workgroup in align_fwd_kernel
+
+// grid (K classes, ceil(B/kAlignQ)), block M*64.  joint[b,k,m] = const[k,m] - 1/2 sum_d (e-mu)^2 * iv
+template <int VEC>
+__global__ void __launch_bounds__(1024)
+align_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ inv_var, const float* __restrict__ row_const,
+                 const float* __restrict__ e, int B, int K, int M, float* __restrict__ L, float* __restrict__ joint) {
+    constexpr int D = 256 * VEC;
+    __shared__ float s_j[kAlignQ][kMaxModes];
+    const int k = blockIdx.x, m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = blockIdx.y * kAlignQ, nq = min(kAlignQ, B - q0);
+    const size_t off = ((size_t)k * M + m) * D;
+    const float4* pm = reinterpret_cast<const float4*>(mu + off);
+    const float4* pi4 = reinterpret_cast<const float4*>(inv_var + off);
+    float4 rm[VEC], ri[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { rm[v] = pm[v * 64 + lane]; ri[v] = pi4[v * 64 + lane]; }
+    const float cst = row_const[k * M + m];
+    for (int qi = 0; qi < nq; ++qi) {
+        const float4* pe = reinterpret_cast<const float4*>(e + (size_t)(q0 + qi) * D);
+        double acc = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float4 x = pe[v * 64 + lane];
+            float d;
+            d = x.x - rm[v].x; acc += (double)((d * d) * ri[v].x);
+            d = x.y - rm[v].y; acc += (double)((d * d) * ri[v].y);
+            d = x.z - rm[v].z; acc += (double)((d * d) * ri[v].z);
+            d = x.w - rm[v].w; acc += (double)((d * d) * ri[v].w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float jv = (float)((double)cst - 0.5 * acc);
+            s_j[qi][m] = jv;
+            joint[((size_t)(q0 + qi) * K + k) * M + m] = jv;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nq) L[(size_t)(q0 + threadIdx.x) * K + k] = lse_modes(s_j[threadIdx.x], M);
+}
+
+// grad_e[b, d] = sum_{k,m} w[b,k,m] (mu - e) * iv.  grid (B, D/256), block 1024 = 16 waves; every
+// wave owns rows km = wave, wave+16, ... and 256 features (one float4 per lane); LDS tree at the end.
+__global__ void __launch_bounds__(1024)
+align_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ inv_var, const float* __restrict__ e,
+                 const float* __restrict__ w, int KM, int D, float* __restrict__ ge) {
+    __shared__ double s_acc[16][256];
+    __shared__ float s_w[2048];
+    const int b = blockIdx.x, c = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4 x = reinterpret_cast<const float4*>(e + (size_t)b * D + c * 256)[lane];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int r0 = 0; r0 < KM; r0 += 2048) {
+        const int n = min(2048, KM - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) s_w[i] = w[(size_t)b * KM + r0 + i];
+        __syncthreads();
+#pragma unroll 4
+        for (int i = wv; i < n; i += 16) {
+            const size_t o = (size_t)(r0 + i) * D + c * 256;
+            const float4 m4 = reinterpret_cast<const float4*>(mu + o)[lane];
+            const float4 i4 = reinterpret_cast<const float4*>(inv_var + o)[lane];
+            const float ww = s_w[i];
+            a0 += (double)(ww * ((m4.x - x.x) * i4.x));
+            a1 += (double)(ww * ((m4.y - x.y) * i4.y));
+            a2 += (double)(ww * ((m4.z - x.z) * i4.z));
+            a3 += (double)(ww * ((m4.w - x.w) * i4.w));
+        }
+    }
+    s_acc[wv][lane * 4 + 0] = a0; s_acc[wv][lane * 4 + 1] = a1; s_acc[wv][lane * 4 + 2] = a2; s_acc[wv][lane * 4 + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_acc[i][threadIdx.x];
+        ge[(size_t)b * D + c * 256 + threadIdx.x] = (float)t;
+    }
+}
+
 template <typename F>
 int dispatch_vec(int D, F&& f) {
     switch (D / 256) {
@@ -345,4 +450,45 @@ extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, flo
     a.nfit = 2; a.xf[0] = x1; a.xf[1] = x2; a.gf[0] = gamma_class; a.gf[1] = gamma_class; a.bf[0] = 1; a.bf[1] = 1;
     a.K = K; a.M = M; a.eps = eps;
     return launch_step(a, D, ua::as_stream(stream));
+}
+
+extern "C" int ua_gmm_prepare_alignment(const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
+                                        float* inv_var, float* row_const, void* stream) {
+    UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(inv_var); UA_CHECK_PTR(row_const);
+    UA_CHECK_ALIGN16(var); UA_CHECK_ALIGN16(inv_var);
+    if (int e = check_envelope(K, M, D)) return e;
+    return dispatch_vec(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        hipLaunchKernelGGL(gmm_prepare_kernel<VEC>, dim3(K), dim3(M * 64), 0, ua::as_stream(stream),
+                           var, pi, M, eps, inv_var, row_const);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+}
+
+extern "C" int ua_align_forward(const float* mu, const float* inv_var, const float* row_const, const float* e,
+                                int32_t B, int32_t K, int32_t M, int32_t D, float* L, float* joint, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(inv_var); UA_CHECK_PTR(row_const); UA_CHECK_PTR(e); UA_CHECK_PTR(L); UA_CHECK_PTR(joint);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(inv_var); UA_CHECK_ALIGN16(e);
+    if (B <= 0) return UA_EINVAL;
+    if (int er = check_envelope(K, M, D)) return er;
+    return dispatch_vec(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        hipLaunchKernelGGL(align_fwd_kernel<VEC>, dim3(K, (B + kAlignQ - 1) / kAlignQ), dim3(M * 64), 0,
+                           ua::as_stream(stream), mu, inv_var, row_const, e, B, K, M, L, joint);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+}
+
+extern "C" int ua_align_backward(const float* mu, const float* inv_var, const float* e, const float* grad_ll,
+                                 int32_t B, int32_t K, int32_t M, int32_t D, float* grad_e, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(inv_var); UA_CHECK_PTR(e); UA_CHECK_PTR(grad_ll); UA_CHECK_PTR(grad_e);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(inv_var); UA_CHECK_ALIGN16(e);
+    if (B <= 0 || K <= 0 || M <= 0 || D <= 0) return UA_EINVAL;
+    if (D % 256 != 0) return UA_EUNSUPPORTED;
+    hipLaunchKernelGGL(align_bwd_kernel, dim3(B, D / 256), dim3(1024), 0, ua::as_stream(stream),
+                       mu, inv_var, e, grad_ll, K * M, D, grad_e);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
 }

@@ -188,7 +188,7 @@ align_loss_kernel(const float* __restrict__ L, const float* __restrict__ joint, 
     const float invK = 1.f / (float)K;
     double sacc = 0.0;
     for (int i = tid; i < n; i += nt) {
-        const int r = i / K, cidx = i % K;
+        const int r = (int)((unsigned)i / (unsigned)K), cidx = i - r * K;
         const float eye = (r == cidx) ? 1.f : 0.f;
         const float dP = -invK * (eye / s1[r] - dg[r] / (s1[r] * s1[r])) - invK * (eye / s2[cidx] - dg[cidx] / (s2[cidx] * s2[cidx]));
         const float l = L[i];
@@ -200,12 +200,13 @@ align_loss_kernel(const float* __restrict__ L, const float* __restrict__ joint, 
     const double S = block_sum(sacc, sd);
     __syncthreads();
     const int amax = s_arg;
-    const int nm = n * M;
-    for (int i = tid; i < nm; i += nt) {
-        const int ik = i / M;
+    const float corr = (float)(-S / ((double)mx * (double)mx));
+    for (int ik = tid; ik < n; ik += nt) {
         float G = P[ik] / mx;
-        if (ik == amax) G += (float)(-S / ((double)mx * (double)mx));
-        grad_ll[i] = G * expf(joint[i] - L[ik]);     // d logsumexp / d joint = softmax
+        if (ik == amax) G += corr;
+        const float l = L[ik];
+        for (int m = 0; m < M; ++m)
+            grad_ll[(size_t)ik * M + m] = G * expf(joint[(size_t)ik * M + m] - l);     // d logsumexp / d joint = softmax
     }
 }
 

@@ -9,47 +9,58 @@ namespace {
 
 using ua::wave_sum;
 
+// One wavefront per row; the row lives in registers (NV float4 per lane), so HBM/L2 sees exactly
+// one read and one write per element.  Columns >= cols (K padding) are written as zeros.
+template <int NV>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
                  float eps, float* __restrict__ y, int64_t ldy, int rows, int cols, int cols_pad) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
-    float* yr = y + (size_t)row * ldy;
-    const int nv = (cols + 3) / 4;                 // float4 chunks (tail chunk masked)
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+    float4* yr = reinterpret_cast<float4*>(y + (size_t)row * ldy);
+    const int nv = (cols + 3) / 4;                 // float4 chunks holding data (tail chunk masked)
+    float4 v[NV];
     double s = 0.0;
-    for (int i = lane; i < nv; i += 64) {
-        const float4 v = reinterpret_cast<const float4*>(xr)[i];
-        const int c0 = 4 * i;
-        s += (double)v.x;
-        if (c0 + 1 < cols) s += (double)v.y;
-        if (c0 + 2 < cols) s += (double)v.z;
-        if (c0 + 3 < cols) s += (double)v.w;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = j * 64 + lane, c0 = 4 * i;
+        v[j] = (i < nv) ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + 0 >= cols) v[j].x = 0.f;
+        if (c0 + 1 >= cols) v[j].y = 0.f;
+        if (c0 + 2 >= cols) v[j].z = 0.f;
+        if (c0 + 3 >= cols) v[j].w = 0.f;
+        s += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
     }
     const float mean = (float)(wave_sum(s) / (double)cols);
     double q = 0.0;
-    for (int i = lane; i < nv; i += 64) {
-        const float4 v = reinterpret_cast<const float4*>(xr)[i];
-        const int c0 = 4 * i;
-        float d = v.x - mean; q += (double)(d * d);
-        if (c0 + 1 < cols) { d = v.y - mean; q += (double)(d * d); }
-        if (c0 + 2 < cols) { d = v.z - mean; q += (double)(d * d); }
-        if (c0 + 3 < cols) { d = v.w - mean; q += (double)(d * d); }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c0 = 4 * (j * 64 + lane);
+        float d;
+        if (c0 + 0 < cols) { d = v[j].x - mean; q += (double)(d * d); }
+        if (c0 + 1 < cols) { d = v[j].y - mean; q += (double)(d * d); }
+        if (c0 + 2 < cols) { d = v[j].z - mean; q += (double)(d * d); }
+        if (c0 + 3 < cols) { d = v[j].w - mean; q += (double)(d * d); }
     }
     const float var = (float)(wave_sum(q) / (double)cols);
     const float rstd = 1.0f / sqrtf(var + eps);
     const int nvp = cols_pad / 4;
-    for (int i = lane; i < nvp; i += 64) {
-        const int c0 = 4 * i;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = j * 64 + lane, c0 = 4 * i;
+        if (i >= nvp) continue;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 < cols) {
-            const float4 v = reinterpret_cast<const float4*>(xr)[i];
-            o.x = (v.x - mean) * rstd * w[c0] + b[c0];
-            if (c0 + 1 < cols) o.y = (v.y - mean) * rstd * w[c0 + 1] + b[c0 + 1];
-            if (c0 + 2 < cols) o.z = (v.z - mean) * rstd * w[c0 + 2] + b[c0 + 2];
-            if (c0 + 3 < cols) o.w = (v.w - mean) * rstd * w[c0 + 3] + b[c0 + 3];
+        if (c0 + 3 < cols) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + c0), bb = *reinterpret_cast<const float4*>(b + c0);
+            o.x = (v[j].x - mean) * rstd * ww.x + bb.x; o.y = (v[j].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[j].z - mean) * rstd * ww.z + bb.z; o.w = (v[j].w - mean) * rstd * ww.w + bb.w;
+        } else {
+            if (c0 + 0 < cols) o.x = (v[j].x - mean) * rstd * w[c0] + b[c0];
+            if (c0 + 1 < cols) o.y = (v[j].y - mean) * rstd * w[c0 + 1] + b[c0 + 1];
+            if (c0 + 2 < cols) o.z = (v[j].z - mean) * rstd * w[c0 + 2] + b[c0 + 2];
         }
-        reinterpret_cast<float4*>(yr)[i] = o;
+        yr[i] = o;
     }
 }
 
@@ -80,8 +91,14 @@ extern "C" int ua_layernorm(const float* x, int64_t ldx, const float* w, const f
     if (rows <= 0 || cols <= 0 || cols_pad < cols) return UA_EINVAL;
     if (ldx % 4 || ldy % 4 || cols_pad % 4) return UA_EALIGN;
     if (ldx < ((cols + 3) / 4) * 4 || ldy < cols_pad) return UA_EINVAL;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, ua::as_stream(stream),
-                       x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad);
+    if (cols_pad > 8192) return UA_EUNSUPPORTED;
+    const int nv = (cols_pad / 4 + 63) / 64;       // float4 per lane
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = ua::as_stream(stream);
+#define UA_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad)
+    if (nv <= 2) UA_LN(2); else if (nv <= 4) UA_LN(4); else if (nv <= 6) UA_LN(6); else if (nv <= 8) UA_LN(8);
+    else if (nv <= 12) UA_LN(12); else if (nv <= 16) UA_LN(16); else if (nv <= 24) UA_LN(24); else UA_LN(32);
+#undef UA_LN
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

@@ -25,10 +25,11 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
         if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
                                     s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
         if (s->res_learning && sample_index0 + j > 0) {                         // :444-476
+            if ((rc = ua_gmm_prepare_alignment(s->var, s->pi, K, M, D, s->eps, s->inv_var, s->row_const, stream))) return rc;
             for (int it = 0; it < s->res_steps; ++it) {
-                if ((rc = ua_gmm_loglik(s->mu, s->var, s->pi, s->e, K, K, M, D, s->eps, s->L, s->joint, nullptr, stream))) return rc;
+                if ((rc = ua_align_forward(s->mu, s->inv_var, s->row_const, s->e, K, K, M, D, s->L, s->joint, stream))) return rc;
                 if ((rc = ua_align_loss(s->L, s->joint, K, M, s->loss, s->grad_ll, stream))) return rc;
-                if ((rc = ua_gmm_loglik_bwd(s->mu, s->var, s->e, s->grad_ll, K, K, M, D, s->eps, s->grad_e, stream))) return rc;
+                if ((rc = ua_align_backward(s->mu, s->inv_var, s->e, s->grad_ll, K, K, M, D, s->grad_e, stream))) return rc;
                 ++adam_step;
                 if (adam_step > 0x7fffffff) return UA_EINVAL;
                 if ((rc = ua_residual_adam(s->text0, s->res, s->adam_m, s->adam_v, s->grad_e, s->e, s->norm, K, D,
