@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Tiny driver for PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): launches the similarity
+kernel (ua_gmm_loglik) and the fused cache step at BASELINE.json configs[4] size a few times, and
+one GEMM of the dominant shape, so per-kernel HBM traffic can be read from the counter CSV.
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_probe.py
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uni_adapter_amd  # noqa: E402,F401
+from uni_adapter_amd import lib  # noqa: E402
+from uni_adapter_amd.lib import GemmEpilogue  # noqa: E402
+
+K, M, D = 4096, 16, 1024
+mu = torch.randn(K, M, D, device='cuda') * 0.03
+var = 1e-4 * (1 + torch.rand(K, M, D, device='cuda'))
+pi = torch.full((K, M), 1.0 / M, device='cuda'); c = pi.clone(); cc = torch.zeros(K, device='cuda')
+x = torch.nn.functional.normalize(torch.randn(1, D, device='cuda'), dim=1)
+g = torch.softmax(torch.randn(1, K, device='cuda'), 1); sc = torch.empty(1, K, device='cuda')
+st = lib.stream_ptr()
+for _ in range(3):
+    lib.call('ua_gmm_loglik', mu.data_ptr(), var.data_ptr(), pi.data_ptr(), x.data_ptr(), 1, K, M, D, 1e-4, sc.data_ptr(), None, None, st)
+for _ in range(3):
+    lib.call('ua_gmm_step_fused', mu.data_ptr(), var.data_ptr(), pi.data_ptr(), c.data_ptr(), cc.data_ptr(), x.data_ptr(), 1, x.data_ptr(),
+             x.data_ptr(), g.data_ptr(), sc.data_ptr(), K, M, D, 1e-4, st)
+Mr, N, Kk = 16416, 3072, 1024
+A = torch.randn(Mr, Kk, device='cuda'); W = torch.randn(N, Kk, device='cuda') / 32; Cc = torch.empty(Mr, N, device='cuda')
+e = GemmEpilogue()
+for _ in range(3):
+    lib.call('ua_gemm', A.data_ptr(), Kk, W.data_ptr(), Kk, Cc.data_ptr(), N, Mr, N, Kk, C.byref(e), st)
+torch.cuda.synchronize()
+print('pmc probe done: similarity algorithmic bytes', 2 * K * M * D * 4, 'fused', 4 * K * M * D * 4, 'gemm A+W+C bytes', 4 * (Mr * Kk + N * Kk + Mr * N))

@@ -165,44 +165,85 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
     if (full) gemm_mainloop<true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
     else      gemm_mainloop<false>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
 
-    // ---- epilogue.  acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*lh, col = li (within the 32x32) ----
+    // ---- epilogue ----------------------------------------------------------------------------
+    // acc[i][j][e] holds row (e&3)+8(e>>2)+4*lh, column li of a 32x32 block: a lane owns single
+    // floats of 64 different rows.  The wave's 64x64 sub-tile is transposed through LDS (free after
+    // the main loop) so that every lane then owns float4s of 4 consecutive columns: bias / BN affine /
+    // activation / residual / max-pool all run on float4s and C is written with 16-byte stores in
+    // 256-byte row segments (64 store instructions per lane become 16).
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EP_LD = 68;                                        // floats per staged row
+    float* stage = lds + wid * 64 * EP_LD;                           // 4 x 17,408 B <= 73,728 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
+    // (no barrier: each wave reads back only what it wrote; LDS ops of one wave complete in order)
     const bool swiglu = g.act == 3;
+    const int lr = lane >> 4, c4 = (lane & 15) * 4;                  // row within a 4-row pass, first column
+    const int ncol0 = n0 + wn * 64 + c4;                             // input column of .x
+    const int nout0 = swiglu ? (n0 + wn * 64) / 2 + c4 : ncol0;      // output column of .x
     const int n_out = swiglu ? g.N / 2 : g.N;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (swiglu && j == 1) break;
-        const int n_in = n0 + wn * 64 + j * 32 + li;                 // column of acc[.][j]
-        const int n_up = n_in + 32;                                  // SwiGLU partner column
-        const int n = swiglu ? (n0 + wn * 64) / 2 + li : n_in;       // output column
-        const bool n_ok = n_in < g.N && n < n_out;
-        const float bj = (g.bias && n_ok) ? g.bias[n_in] : 0.f;
-        const float bu = (swiglu && g.bias && n_ok) ? g.bias[n_up] : 0.f;
-        const float sc = (g.scale && n_ok) ? g.scale[n_in] : 1.f;
-        const float sh = (g.shift && n_ok) ? g.shift[n_in] : 0.f;
-        float pmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < g.M && n_ok) {
-                    float v = acc[i][j][e] + bj;
-                    if (g.rga) v += g.rga[(size_t)(m / g.group_rows) * g.ldg + n_in];
-                    if (g.scale) v = v * sc;
-                    if (g.shift) v = v + sh;
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    else if (g.act == 2) v = gelu_erf(v);
-                    else if (swiglu) v = silu(v) * (acc[i][1][e] + bu);
-                    if (g.residual) v += g.residual[(size_t)m * g.ldr + n];
-                    if (g.C) g.C[(size_t)m * g.ldc + n] = v;
-                    pmax = fmaxf(pmax, v);
-                }
-            }
+    const bool active = swiglu ? (c4 < 32) : true;                   // SwiGLU: gate lanes produce output
+    auto ld4 = [&](const float* p, int n, int lim, float fill) {     // guarded float4 of a per-column vector
+        float4 r = make_float4(fill, fill, fill, fill);
+        if (p) {
+            if (n + 3 < lim) r = *reinterpret_cast<const float4*>(p + n);
+            else { if (n < lim) r.x = p[n]; if (n + 1 < lim) r.y = p[n + 1]; if (n + 2 < lim) r.z = p[n + 2]; }
         }
-        if (g.pool) {                                                  // max over this wave's 64 rows
-            pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
-            const int m_grp = (m0 + wm * 64) / 64;
-            if (lh == 0 && n_ok && (m0 + wm * 64) < g.M) g.pool[(size_t)m_grp * g.ldp + n] = pmax;
+        return r;
+    };
+    const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
+    const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);
+    const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
+    float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const int mbase = m0 + wm * 64;
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int r = p * 4 + lr, m = mbase + r;
+        float4 v = *reinterpret_cast<const float4*>(stage + r * EP_LD + c4);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        const bool row_ok = m < g.M;
+        if (g.rga && row_ok) {
+            const float4 a = ld4(g.rga + (size_t)(m / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (g.scale) { v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+        if (g.shift) { v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
+        if (g.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (g.act == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        else if (swiglu) {
+            // the up-projection of column c sits 32 columns to the right = 8 lanes up in this row
+            float4 u;
+            u.x = __shfl_down(v.x, 8); u.y = __shfl_down(v.y, 8); u.z = __shfl_down(v.z, 8); u.w = __shfl_down(v.w, 8);
+            v.x = silu(v.x) * u.x; v.y = silu(v.y) * u.y; v.z = silu(v.z) * u.z; v.w = silu(v.w) * u.w;
+        }
+        if (row_ok && active) {
+            if (g.residual) {
+                const float4 a = ld4(g.residual + (size_t)m * g.ldr, nout0, n_out, 0.f);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            if (g.C) {
+                float* c = g.C + (size_t)m * g.ldc + nout0;
+                if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(c) = v;
+                else { if (nout0 < n_out) c[0] = v.x; if (nout0 + 1 < n_out) c[1] = v.y; if (nout0 + 2 < n_out) c[2] = v.z; }
+            }
+            pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w);
+        }
+    }
+    if (g.pool) {                                                    // max over this wave's 64 rows
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            pm.x = fmaxf(pm.x, __shfl_xor(pm.x, o)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, o));
+            pm.z = fmaxf(pm.z, __shfl_xor(pm.z, o)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, o));
+        }
+        if (lr == 0 && mbase < g.M) {
+            float* q = g.pool + (size_t)(mbase / 64) * g.ldp + nout0;
+            if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = pm;
+            else { if (nout0 < n_out) q[0] = pm.x; if (nout0 + 1 < n_out) q[1] = pm.y; if (nout0 + 2 < n_out) q[2] = pm.z; }
         }
     }
 }
@@ -231,6 +272,13 @@ extern "C" int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw,
     if (!C && !g.pool) return UA_EINVAL;
     const int n_out = g.act == 3 ? N / 2 : N;
     if (C && ldc < n_out) return UA_EINVAL;
+    // float4 epilogue: row starts of C / residual / pool / rowgroup_add must be 16-byte aligned
+    if (C && (ldc % 4 || (reinterpret_cast<uintptr_t>(C) & 15))) return UA_EALIGN;
+    if (g.residual && (g.ldr % 4 || (reinterpret_cast<uintptr_t>(g.residual) & 15))) return UA_EALIGN;
+    if (g.pool && (g.ldp % 4 || (reinterpret_cast<uintptr_t>(g.pool) & 15))) return UA_EALIGN;
+    if (g.rga && (g.ldg % 4 || (reinterpret_cast<uintptr_t>(g.rga) & 15))) return UA_EALIGN;
+    if ((g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 15)) || (g.scale && (reinterpret_cast<uintptr_t>(g.scale) & 15)) ||
+        (g.shift && (reinterpret_cast<uintptr_t>(g.shift) & 15))) return UA_EALIGN;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
     const size_t lds = (size_t)4 * TILE_F * sizeof(float);           // 73,728 B
