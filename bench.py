@@ -50,9 +50,33 @@ def parse():
     ap.add_argument('--depth', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-similarity', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=4)
+    ap.add_argument('--cpu-samples', type=int, default=3)
     ap.add_argument('--no-res-learning', action='store_true')
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may really use: min(affinity, cgroup cpu quota, UA_CPU_THREADS); the GPU
+    boxes expose 256 logical CPUs but give one job a 16-core share, and oversubscribing the torch
+    thread pool there is ~100x slower than matching it."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    cap = int(os.environ.get('UA_CPU_THREADS', '16'))
+    return max(1, min(n, cap))
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        return d['kernels'][kernel]['traffic_bytes']
+    except Exception:
+        return None
 
 
 def similarity_roofline(dev):
@@ -88,7 +112,8 @@ def similarity_roofline(dev):
         ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                     'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'bytes_per_launch': nbytes,
+                     'frac': round(gbs / PEAK_HBM_GBS, 4),
+                     'traffic': pmc_traffic('gmm_loglik_kernel<4>' if name == 'predict' else 'gmm_step_kernel<4>'), 'bytes_per_launch': nbytes,
                      'ms_per_launch': round(ms, 4), 'shape': {'K': K, 'M': M, 'D': D, 'dtype': 'f32'}}
     return out
 
@@ -96,8 +121,7 @@ def similarity_roofline(dev):
 def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
     """Oracle (kind 'port') timed on the host cores on the first n samples of the same stream."""
     from oracle import ref_cpu as O               # baseline leg only
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get('UA_CPU_THREADS', ncpu)))))
+    torch.set_num_threads(host_cores())
     log(f'cpu baseline: {torch.get_num_threads()} threads, {n} samples')
     s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
     enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
