@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no-similarity', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=3)
     ap.add_argument('--no-res-learning', action='store_true')
+    ap.add_argument('--precision', choices=['f32', 'split'], default=os.environ.get('UA_GEMM_PRECISION', 'f32'),
+                    help="GEMM mode: 'f32' exact-f32 MFMA, 'split' 3xf16-split MFMA (fp32-accurate)")
     return ap.parse_args()
 
 
@@ -166,7 +168,8 @@ def main():
     gpath = os.path.join(ROOT, 'tests', 'golden', 'g2_stream_modelnet40.npz')
     text = torch.from_numpy(np.load(gpath)['text']) if os.path.exists(gpath) else synthetic.text_bank(40, 1024)
     sd = synthetic.uni3d_state_dict(0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=a.depth, device=dev)
-    model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev)
+    model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
+                                            precision=a.precision)
     n_local, n_global = a.chunk, a.chunk * world
     total_steps = a.warmup + a.steps
     # the whole synthetic stream is resident in HBM before the timed region (same stream on every rank)

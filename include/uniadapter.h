@@ -158,7 +158,8 @@ int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
  *   act: 0 none | 1 ReLU | 2 GELU(erf) | 3 SwiGLU (columns come in blocks of 32 gate / 32 up:
  *        out[:, j] = silu(gate)*up, N_out = N/2; timm SwiGLU of EvaBlock)
  *   v += residual[m, n]
- *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64)    */
+ *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64)
+ *   split_out (optional): the same output as an H32L32 split-precision matrix (see ua_split_f16)  */
 typedef struct {
     const float* bias;
     const float* scale;
@@ -167,6 +168,7 @@ typedef struct {
     int32_t      act;
     const float* residual;     int64_t ldr;
     float*       pool_out;     int64_t ldp; int32_t pool_rows;
+    void*        split_out;    int64_t ld_split; float split_scale;  /* optional H32L32 copy of the output */
 } ua_gemm_epilogue;
 
 /* C (M,N) = A (M,K) @ W (N,K)^T with fused epilogue: every Linear / Conv1d(k=1) of the encoder
@@ -175,10 +177,35 @@ typedef struct {
 int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
             int32_t M, int32_t N, int32_t K, const ua_gemm_epilogue* ep, void* stream);
 
+/* Split-precision ("H32L32") operands for ua_gemm_split.  A (rows, cols) fp32 matrix is stored
+ * with the row pitch of fp32 (ld*4 bytes, ld % 32 == 0); each group of 32 consecutive columns is 32
+ * fp16 "hi" values (64 B) followed by 32 fp16 "lo" values (64 B) with x*scale = hi + lo, hi =
+ * rn16(x*scale), lo = rn16(x*scale - hi); scale is a power of two.  Columns cols..cols_pad-1 are
+ * zero.  ua_split_f16 converts an fp32 matrix (weights at load time, activations that no producer
+ * kernel emits in split form).                                                                  */
+int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols,
+                 int32_t cols_pad, float scale, void* stream);
+
+/* C = A @ W^T with the accuracy of an fp32 GEMM on the f16 matrix cores: both operands are
+ * H32L32 pairs and the product is evaluated as hi*hi + hi*lo + lo*hi (three
+ * v_mfma_f32_32x32x16_f16 per block, fp32 accumulate; the dropped lo*lo term is 2^-22 relative).
+ * gfx950 has no TF32/xf32 path and its f32 MFMA runs at 1/16 of the f16 rate, so this is 16/3 x
+ * the f32-MFMA roofline at the same numerical quality (measured: tests/test_gpu_kernels.py).
+ * A: (M, K) split, scale a_scale; W: (N, K) split, scale w_scale; accumulators are multiplied by
+ * 1/(a_scale*w_scale) before the epilogue.  K % 32 == 0, lda/ldw % 32 == 0.  Same epilogue as
+ * ua_gemm.  Replaces the same reference Linear/Conv1d call sites as ua_gemm.                     */
+int ua_gemm_split(const void* A, int64_t lda, float a_scale, const void* W, int64_t ldw, float w_scale,
+                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                  const ua_gemm_epilogue* ep, void* stream);
+
 /* LayerNorm over the last dim (timm LayerNorm eps 1e-6): rows x cols, cols % 4 == 0, cols<=8192.
  * Columns cols..cols_pad-1 of y are zero-filled (GEMM K padding).                              */
 int ua_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
                  float* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad, void* stream);
+/* Same, writing the result as an H32L32 split matrix (cols_pad % 32 == 0) for ua_gemm_split.     */
+int ua_layernorm_split(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                       void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad,
+                       float scale, void* stream);
 
 /* Multi-head self-attention softmax(q k^T / sqrt(hd)) v of timm EvaAttention without rope
  * (models/point_encoder.py:217-218) for Bc clouds of G patch tokens + 1 CLS token.

@@ -19,12 +19,13 @@ def _clouds(B, N, seed):
     return torch.cat([xyz, rgb], -1)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'split'])
 @pytest.mark.parametrize('B,trans_dim,depth,G,embed', [(2, 128, 2, 128, 64), (3, 256, 1, 256, 128)])
-def test_encode_pc_small(B, trans_dim, depth, G, embed):
+def test_encode_pc_small(B, trans_dim, depth, G, embed, precision):
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
     sd = O.make_uni3d_state_dict(7, trans_dim=trans_dim, embed_dim=embed, enc_dim=512, depth=depth)
     pc = _clouds(B, 1024, 3)
-    model = create_uni3d_from_state_dict(sd, num_group=G, group_size=64, num_heads=trans_dim // 64)
+    model = create_uni3d_from_state_dict(sd, num_group=G, group_size=64, num_heads=trans_dim // 64, precision=precision)
     model.eval()
     out, tokens = model.point_encoder(pc[:, :, :3].cuda(), pc[:, :, 3:].cuda(), return_tokens=True)
     sd64 = {k: v.double() for k, v in sd.items()}
@@ -42,13 +43,15 @@ def test_encode_pc_small(B, trans_dim, depth, G, embed):
     assert (1 - cos).max().item() < 1e-9
 
 
-def test_encode_pc_uni3d_large_shape_one_block():
+@pytest.mark.parametrize('precision', ['f32', 'split'])
+def test_encode_pc_uni3d_large_shape_one_block(precision):
     """Full Uni3D-L width (1024, 16 heads, hidden 2730, G=512) with 2 of the 24 blocks: exercises
-    the real GEMM shapes incl. the K=2730->2752 padding and the SwiGLU interleave."""
+    the real GEMM shapes incl. the K=2730->2752 padding and the SwiGLU interleave, in both GEMM
+    modes (exact-f32 MFMA / 3xf16-split MFMA) at the SAME tolerance."""
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
     sd = O.make_uni3d_state_dict(11, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=2)
     pc = _clouds(2, 1024, 5)
-    model = create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16)
+    model = create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16, precision=precision)
     out = model.encode_pc(pc.cuda())
     ref32 = O.uni3d_encode_pc(pc, sd, 512, 64, 16)
     cos = torch.nn.functional.cosine_similarity(out.cpu().double(), ref32.double(), dim=1)
@@ -65,3 +68,23 @@ def test_encoder_batch_invariance():
     full = model.encode_pc(pc)
     one = torch.cat([model.encode_pc(pc[i:i + 1]) for i in range(5)])
     assert torch.equal(full, one)
+
+
+def test_split_mode_tracks_f32_mode_full_depth():
+    """24-block Uni3D-L: features of the split-GEMM mode vs the exact-f32 mode (both HIP) - the
+    deviation must stay at fp32 round-off level (cosine 1 - 1e-9, 100*cos logits within 1e-3)."""
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd import synthetic
+    sd = synthetic.uni3d_state_dict(0, depth=24, device='cuda')
+    pc = _clouds(4, 1024, 13).cuda()
+    text = synthetic.text_bank(40, 1024, 0, device='cuda')
+    outs = {}
+    for prec in ('f32', 'split'):
+        m = create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16, precision=prec)
+        outs[prec] = torch.nn.functional.normalize(m.encode_pc(pc), dim=1)
+        del m
+    cos = (outs['f32'].double() * outs['split'].double()).sum(1)
+    dl = (100.0 * (outs['f32'] - outs['split']) @ text.T).abs().max().item()
+    print('1-cos', (1 - cos).max().item(), 'max |d logit|', dl)
+    assert (1 - cos).max().item() < 1e-9
+    assert dl < 1e-3

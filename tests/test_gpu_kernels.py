@@ -444,3 +444,79 @@ def test_alignment_fast_path_equals_generic_kernels(ua, golden_dir):
     ref = ex.grad
     assert (g1.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     assert (g0.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------ split-precision GEMM
+def _split(ua, x, cols_pad=None, scale=1.0):
+    rows, cols = x.shape
+    cols_pad = cols_pad or (cols + 31) // 32 * 32
+    y = torch.empty(rows, cols_pad, device='cuda')          # same bytes as fp32: 4 per column
+    ua.call('ua_split_f16', ua.ptr(x), x.stride(0), y.data_ptr(), cols_pad, rows, cols, cols_pad, float(scale), ua.stream_ptr())
+    return y
+
+
+def test_split_format_roundtrip(ua):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(37, 100, generator=g) * torch.exp(2 * torch.randn(37, 1, generator=g))
+    y = _split(ua, dev(x), 128, 4.0).cpu()
+    raw = y.view(torch.float16).reshape(37, 4, 2, 32)        # [row][group][hi|lo][32]
+    rec = (raw[:, :, 0].double() + raw[:, :, 1].double()).reshape(37, 128) / 4.0
+    assert (rec[:, :100] - x.double()).abs().max().item() <= 2 ** -21 * x.abs().max().item()
+    assert torch.equal(rec[:, 100:], torch.zeros(37, 28, dtype=torch.float64))
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 32), (513, 1024, 1024), (16416, 1024, 1024), (1000, 5504, 1024), (4104, 1024, 2752), (300, 200, 96)])
+def test_gemm_split_matches_fp32_accuracy(ua, M, N, K):
+    """3xf16-split MFMA GEMM: error vs fp64 must be no worse than 2x the exact-f32 MFMA kernel's."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)); W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    Ad, Wd = dev(A), dev(W)
+    ws = 2.0 ** math.floor(math.log2(30000.0 / W.abs().max().item())); ws = min(ws, 4096.0)
+    As, Ws = _split(ua, Ad, scale=1.0), _split(ua, Wd, scale=ws)
+    from uni_adapter_amd.lib import GemmEpilogue
+    e = GemmEpilogue(); bd = dev(b); e.bias = bd.data_ptr()
+    C1 = torch.zeros(M, N, device='cuda'); C0 = torch.zeros(M, N, device='cuda')
+    ua.call('ua_gemm_split', As.data_ptr(), As.stride(0), 1.0, Ws.data_ptr(), Ws.stride(0), ws, ua.ptr(C1), N, M, N, K, C.byref(e), ua.stream_ptr())
+    ua.call('ua_gemm', ua.ptr(Ad), K, ua.ptr(Wd), K, ua.ptr(C0), N, M, N, K, C.byref(e), ua.stream_ptr())
+    ref = A.double() @ W.double().T + b.double()
+    e1 = (C1.cpu().double() - ref).abs(); e0 = (C0.cpu().double() - ref).abs()
+    print(f'split max {e1.max():.3e} rms {e1.pow(2).mean().sqrt():.3e} | f32 mfma max {e0.max():.3e} rms {e0.pow(2).mean().sqrt():.3e}')
+    assert e1.pow(2).mean().sqrt().item() <= 2.0 * e0.pow(2).mean().sqrt().item() + 1e-9
+    assert e1.max().item() <= 3.0 * e0.max().item() + 1e-7
+
+
+def test_gemm_split_epilogues_and_split_output(ua):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 192, 64
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / 8; b = torch.randn(N, generator=g)
+    sc = 1 + 0.1 * torch.randn(N, generator=g); sh = torch.randn(N, generator=g); rga = torch.randn(M // 64, N, generator=g)
+    As, Ws = _split(ua, dev(A)), _split(ua, dev(W), scale=256.0)
+    from uni_adapter_amd.lib import GemmEpilogue
+    e = GemmEpilogue(); keep = [dev(b), dev(sc), dev(sh), dev(rga)]
+    e.bias, e.scale, e.shift, e.rowgroup_add = [t.data_ptr() for t in keep]; e.ldg = N; e.group_rows = 64; e.act = 1
+    pool = torch.empty(M // 64, N, device='cuda'); e.pool_out = pool.data_ptr(); e.ldp = N; e.pool_rows = 64
+    Cs = torch.zeros(M, N, device='cuda'); e.split_out = Cs.data_ptr(); e.ld_split = N; e.split_scale = 2.0
+    Cd = torch.zeros(M, N, device='cuda')
+    ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
+    base = A.double() @ W.double().T + b.double()
+    ref = torch.relu((base + rga.double().repeat_interleave(64, 0)) * sc.double() + sh.double())
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+    assert (pool.cpu().double() - ref.reshape(M // 64, 64, N).max(1)[0]).abs().max().item() < 5e-5
+    raw = Cs.cpu().view(torch.float16).reshape(M, N // 32, 2, 32)
+    rec = (raw[:, :, 0].double() + raw[:, :, 1].double()).reshape(M, N) / 2.0
+    assert (rec - Cd.cpu().double()).abs().max().item() <= 2 ** -20 * ref.abs().max().item()
+
+
+def test_layernorm_split_output(ua):
+    g = torch.Generator().manual_seed(6)
+    rows, cols, pad = 100, 2730, 2752
+    x = torch.zeros(rows, pad); x[:, :cols] = torch.randn(rows, cols, generator=g) * 3 + 1.5
+    w = torch.randn(cols, generator=g); b = torch.randn(cols, generator=g)
+    y = torch.full((rows, pad), 9.0, device='cuda')
+    ua.call('ua_layernorm_split', ua.ptr(dev(x)), pad, ua.ptr(dev(w)), ua.ptr(dev(b)), 1e-6, y.data_ptr(), pad, rows, cols, pad, 8.0, ua.stream_ptr())
+    raw = y.cpu().view(torch.float16).reshape(rows, pad // 32, 2, 32)
+    rec = (raw[:, :, 0].double() + raw[:, :, 1].double()).reshape(rows, pad) / 8.0
+    ref = torch.nn.functional.layer_norm(x[:, :cols].double(), (cols,), w.double(), b.double(), 1e-6)
+    assert (rec[:, :cols] - ref).abs().max().item() < 2e-5
+    assert torch.equal(rec[:, cols:], torch.zeros(rows, pad - cols, dtype=torch.float64))

@@ -45,6 +45,27 @@ def gemm():
         print(f'{name:18s} M={M:6d} N={N:5d} K={K:5d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:6.1f})  frac {fl / med / 1e9 / 157.3:.3f}')
 
 
+def gemm_split():
+    print('== ua_gemm_split (3 x f16 MFMA, fp32-accurate); fp32-equivalent FLOPs; f32-MFMA peak 157.3 TF')
+    shapes = [(16416, 3072, 1024, 'qkv Bc=32'), (16416, 1024, 1024, 'proj'), (16416, 5504, 1024, 'fc1 swiglu'), (16416, 1024, 2752, 'fc2'),
+              (262144, 512, 512, 'conv4 8 clouds'), (262144, 512, 256, 'conv3'), (262144, 256, 128, 'conv2'),
+              (1026, 3072, 1024, 'qkv Bc=2'), (4104, 3072, 1024, 'qkv Bc=8'), (8192, 8192, 8192, 'square 8k')]
+    for M, N, K, name in shapes:
+        A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5
+        As = torch.empty(M, K, device='cuda'); Ws = torch.empty(N, K, device='cuda')
+        st = lib.stream_ptr()
+        lib.call('ua_split_f16', A.data_ptr(), K, As.data_ptr(), K, M, K, K, 1.0, st)
+        lib.call('ua_split_f16', W.data_ptr(), K, Ws.data_ptr(), K, N, K, K, 1024.0, st)
+        act = 3 if 'swiglu' in name else 0
+        Cc = torch.empty(M, N // 2 if act == 3 else N, device='cuda')
+        b = torch.randn(N, device='cuda')
+        e = GemmEpilogue(); e.bias = b.data_ptr(); e.act = act
+        fn = lambda: lib.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 1024.0, Cc.data_ptr(), Cc.stride(0), M, N, K, C.byref(e), st)
+        med, mn = timeit(fn)
+        fl = 2.0 * M * N * K
+        print(f'{name:18s} M={M:6d} N={N:5d} K={K:5d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s-equiv (best {fl / mn / 1e9:6.1f})  vs f32-mfma peak {fl / med / 1e9 / 157.3:.2f}x')
+
+
 def attn():
     print('== ua_attention (fp32 MFMA)')
     for Bc in (2, 8, 32):

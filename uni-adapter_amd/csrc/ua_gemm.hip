@@ -19,30 +19,24 @@
 // Workgroup ids are remapped so that each XCD (blockIdx % 8) owns a contiguous band of row
 // panels: the A panel of a band is fetched from HBM once and re-used from that XCD's L2 by all
 // column tiles.
-#include "ua_common.h"
+#include "ua_gemm_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using ua::f32x16;
+using ua::EpiArgs;
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_LD = BK + 4;                       // floats per LDS row
 constexpr int TILE_F = BM * LDS_LD;                  // floats per operand tile
 
 struct GemmArgs {
-    const float* A; const float* W; float* C;
-    long long lda, ldw, ldc;
+    const float* A; const float* W;
+    long long lda, ldw;
     int M, N, K;
-    const float* bias; const float* scale; const float* shift;
-    const float* rga; long long ldg; int group_rows;
-    int act;
-    const float* residual; long long ldr;
-    float* pool; long long ldp;
+    EpiArgs ep;
     int tiles_n, n_tiles;
 };
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 // Branch-free guarded 16-byte load: the address is clamped into the matrix (always legal), the
 // value is zeroed by a select when the element is outside (rows >= nrows, k >= K).  Out-of-range
@@ -132,9 +126,13 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, int m0, int n0,
 __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
     // ---- XCD-aware tile id (bijective for any n_tiles) ----
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = g.n_tiles >> 3, r = g.n_tiles & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int n_full = (g.M / BM) * g.tiles_n;       // tiles of complete row panels: balanced over XCDs
+    int tile = bid;                                  // tiles of a partial last row panel keep block order
+    if (bid < n_full) {
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = n_full >> 3, r = n_full & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -165,87 +163,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_mfma_kernel(GemmArgs g) {
     if (full) gemm_mainloop<true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
     else      gemm_mainloop<false>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
 
-    // ---- epilogue ----------------------------------------------------------------------------
-    // acc[i][j][e] holds row (e&3)+8(e>>2)+4*lh, column li of a 32x32 block: a lane owns single
-    // floats of 64 different rows.  The wave's 64x64 sub-tile is transposed through LDS (free after
-    // the main loop) so that every lane then owns float4s of 4 consecutive columns: bias / BN affine /
-    // activation / residual / max-pool all run on float4s and C is written with 16-byte stores in
-    // 256-byte row segments (64 store instructions per lane become 16).
+    // ---- epilogue: transpose the wave's 64x64 sub-tile through LDS (free after the main loop) and
+    // run the shared float4 epilogue (ua_gemm_common.h) ----
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int EP_LD = 68;                                        // floats per staged row
-    float* stage = lds + wid * 64 * EP_LD;                           // 4 x 17,408 B <= 73,728 B
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * EP_LD + j * 32 + li] = acc[i][j][e];
+    float* stage = lds + wid * 64 * ua::EP_LD;                       // 4 x 17,408 B <= 73,728 B
+    ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
     // (no barrier: each wave reads back only what it wrote; LDS ops of one wave complete in order)
-    const bool swiglu = g.act == 3;
-    const int lr = lane >> 4, c4 = (lane & 15) * 4;                  // row within a 4-row pass, first column
-    const int ncol0 = n0 + wn * 64 + c4;                             // input column of .x
-    const int nout0 = swiglu ? (n0 + wn * 64) / 2 + c4 : ncol0;      // output column of .x
-    const int n_out = swiglu ? g.N / 2 : g.N;
-    const bool active = swiglu ? (c4 < 32) : true;                   // SwiGLU: gate lanes produce output
-    auto ld4 = [&](const float* p, int n, int lim, float fill) {     // guarded float4 of a per-column vector
-        float4 r = make_float4(fill, fill, fill, fill);
-        if (p) {
-            if (n + 3 < lim) r = *reinterpret_cast<const float4*>(p + n);
-            else { if (n < lim) r.x = p[n]; if (n + 1 < lim) r.y = p[n + 1]; if (n + 2 < lim) r.z = p[n + 2]; }
-        }
-        return r;
-    };
-    const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
-    const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);
-    const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
-    float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    const int mbase = m0 + wm * 64;
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-        const int r = p * 4 + lr, m = mbase + r;
-        float4 v = *reinterpret_cast<const float4*>(stage + r * EP_LD + c4);
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        const bool row_ok = m < g.M;
-        if (g.rga && row_ok) {
-            const float4 a = ld4(g.rga + (size_t)(m / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-        if (g.scale) { v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
-        if (g.shift) { v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
-        if (g.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        else if (g.act == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-        else if (swiglu) {
-            // the up-projection of column c sits 32 columns to the right = 8 lanes up in this row
-            float4 u;
-            u.x = __shfl_down(v.x, 8); u.y = __shfl_down(v.y, 8); u.z = __shfl_down(v.z, 8); u.w = __shfl_down(v.w, 8);
-            v.x = silu(v.x) * u.x; v.y = silu(v.y) * u.y; v.z = silu(v.z) * u.z; v.w = silu(v.w) * u.w;
-        }
-        if (row_ok && active) {
-            if (g.residual) {
-                const float4 a = ld4(g.residual + (size_t)m * g.ldr, nout0, n_out, 0.f);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-            }
-            if (g.C) {
-                float* c = g.C + (size_t)m * g.ldc + nout0;
-                if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(c) = v;
-                else { if (nout0 < n_out) c[0] = v.x; if (nout0 + 1 < n_out) c[1] = v.y; if (nout0 + 2 < n_out) c[2] = v.z; }
-            }
-            pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w);
-        }
-    }
-    if (g.pool) {                                                    // max over this wave's 64 rows
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            pm.x = fmaxf(pm.x, __shfl_xor(pm.x, o)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, o));
-            pm.z = fmaxf(pm.z, __shfl_xor(pm.z, o)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, o));
-        }
-        if (lr == 0 && mbase < g.M) {
-            float* q = g.pool + (size_t)(mbase / 64) * g.ldp + nout0;
-            if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = pm;
-            else { if (nout0 < n_out) q[0] = pm.x; if (nout0 + 1 < n_out) q[1] = pm.y; if (nout0 + 2 < n_out) q[2] = pm.z; }
-        }
-    }
+    ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
 }  // namespace
@@ -258,27 +182,8 @@ extern "C" int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw,
     if (K % 4 || lda % 4 || ldw % 4) return UA_EALIGN;
     if (lda < K || ldw < K) return UA_EINVAL;
     GemmArgs g{};
-    g.A = A; g.W = W; g.C = C; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-    if (ep) {
-        g.bias = ep->bias; g.scale = ep->scale; g.shift = ep->shift;
-        g.rga = ep->rowgroup_add; g.ldg = ep->ldg; g.group_rows = ep->group_rows;
-        g.act = ep->act; g.residual = ep->residual; g.ldr = ep->ldr;
-        g.pool = ep->pool_out; g.ldp = ep->ldp;
-        if (g.act < 0 || g.act > 3) return UA_EINVAL;
-        if (g.rga && g.group_rows <= 0) return UA_EINVAL;
-        if (g.pool && (ep->pool_rows != 64 || M % 64 != 0)) return UA_EUNSUPPORTED;
-        if (g.act == 3 && (N % 64 != 0 || g.rga || g.scale || g.shift)) return UA_EUNSUPPORTED;
-    }
-    if (!C && !g.pool) return UA_EINVAL;
-    const int n_out = g.act == 3 ? N / 2 : N;
-    if (C && ldc < n_out) return UA_EINVAL;
-    // float4 epilogue: row starts of C / residual / pool / rowgroup_add must be 16-byte aligned
-    if (C && (ldc % 4 || (reinterpret_cast<uintptr_t>(C) & 15))) return UA_EALIGN;
-    if (g.residual && (g.ldr % 4 || (reinterpret_cast<uintptr_t>(g.residual) & 15))) return UA_EALIGN;
-    if (g.pool && (g.ldp % 4 || (reinterpret_cast<uintptr_t>(g.pool) & 15))) return UA_EALIGN;
-    if (g.rga && (g.ldg % 4 || (reinterpret_cast<uintptr_t>(g.rga) & 15))) return UA_EALIGN;
-    if ((g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 15)) || (g.scale && (reinterpret_cast<uintptr_t>(g.scale) & 15)) ||
-        (g.shift && (reinterpret_cast<uintptr_t>(g.shift) & 15))) return UA_EALIGN;
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    if (int e = ua::fill_epi(g.ep, ep, M, N, C, ldc)) return e;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
     const size_t lds = (size_t)4 * TILE_F * sizeof(float);           // 73,728 B

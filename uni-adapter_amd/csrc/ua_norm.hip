@@ -3,7 +3,7 @@
 // Reference semantics: timm LayerNorm (eps 1e-6) inside EvaBlock / visual.norm / fc_norm
 // (models/point_encoder.py:217-220); token assembly models/point_encoder.py:198-208.
 // Both are HBM/L2-streaming ops: one wavefront per row, 16-byte accesses, fp64 moments.
-#include "ua_common.h"
+#include "ua_gemm_common.h"
 
 namespace {
 
@@ -11,10 +11,11 @@ using ua::wave_sum;
 
 // One wavefront per row; the row lives in registers (NV float4 per lane), so HBM/L2 sees exactly
 // one read and one write per element.  Columns >= cols (K padding) are written as zeros.
-template <int NV>
+// SPLIT: the result is written as an H32L32 split-precision matrix (operand of ua_gemm_split).
+template <int NV, bool SPLIT>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
-                 float eps, float* __restrict__ y, int64_t ldy, int rows, int cols, int cols_pad) {
+                 float eps, float* __restrict__ y, int64_t ldy, int rows, int cols, int cols_pad, float split_scale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
@@ -60,7 +61,15 @@ layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restri
             if (c0 + 1 < cols) o.y = (v[j].y - mean) * rstd * w[c0 + 1] + b[c0 + 1];
             if (c0 + 2 < cols) o.z = (v[j].z - mean) * rstd * w[c0 + 2] + b[c0 + 2];
         }
-        yr[i] = o;
+        if (SPLIT) {
+            ua::f16x4 hi, lo;
+            ua::split4(o, split_scale, hi, lo);
+            unsigned char* q = reinterpret_cast<unsigned char*>(y) + (size_t)row * ldy * 4 + ua::split_col_off(c0);
+            *reinterpret_cast<ua::f16x4*>(q) = hi;
+            *reinterpret_cast<ua::f16x4*>(q + 64) = lo;
+        } else {
+            yr[i] = o;
+        }
     }
 }
 
@@ -95,7 +104,28 @@ extern "C" int ua_layernorm(const float* x, int64_t ldx, const float* w, const f
     const int nv = (cols_pad / 4 + 63) / 64;       // float4 per lane
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t st = ua::as_stream(stream);
-#define UA_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad)
+#define UA_LN(NV) hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad, 1.0f)
+    if (nv <= 2) UA_LN(2); else if (nv <= 4) UA_LN(4); else if (nv <= 6) UA_LN(6); else if (nv <= 8) UA_LN(8);
+    else if (nv <= 12) UA_LN(12); else if (nv <= 16) UA_LN(16); else if (nv <= 24) UA_LN(24); else UA_LN(32);
+#undef UA_LN
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_layernorm_split(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                                  void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad,
+                                  float scale, void* stream) {
+    UA_CHECK_PTR(x); UA_CHECK_PTR(w); UA_CHECK_PTR(b); UA_CHECK_PTR(y);
+    UA_CHECK_ALIGN16(x); UA_CHECK_ALIGN16(y);
+    if (rows <= 0 || cols <= 0 || cols_pad < cols || !(scale > 0.f)) return UA_EINVAL;
+    if (ldx % 4 || ldy % 32 || cols_pad % 32) return UA_EALIGN;
+    if (ldx < ((cols + 3) / 4) * 4 || ldy < cols_pad) return UA_EINVAL;
+    if (cols_pad > 8192) return UA_EUNSUPPORTED;
+    const int nv = (cols_pad / 4 + 63) / 64;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = ua::as_stream(stream);
+    float* yf = reinterpret_cast<float*>(y);
+#define UA_LN(NV) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, x, ldx, w, b, eps, yf, ldy, rows, cols, cols_pad, scale)
     if (nv <= 2) UA_LN(2); else if (nv <= 4) UA_LN(4); else if (nv <= 6) UA_LN(6); else if (nv <= 8) UA_LN(8);
     else if (nv <= 12) UA_LN(12); else if (nv <= 16) UA_LN(16); else if (nv <= 24) UA_LN(24); else UA_LN(32);
 #undef UA_LN

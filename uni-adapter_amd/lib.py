@@ -27,7 +27,8 @@ class GemmEpilogue(C.Structure):
                 ('rowgroup_add', _p), ('ldg', _i64), ('group_rows', _i32),
                 ('act', _i32),
                 ('residual', _p), ('ldr', _i64),
-                ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32)]
+                ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32),
+                ('split_out', _p), ('ld_split', _i64), ('split_scale', _f)]
 
 
 class TtaState(C.Structure):
@@ -62,6 +63,9 @@ SIGNATURES = {
     'ua_knn_group': [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p],
     'ua_gemm': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
     'ua_layernorm': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _p],
+    'ua_layernorm_split': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _f, _p],
+    'ua_split_f16': [_p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p],
+    'ua_gemm_split': [_p, _i64, _f, _p, _i64, _f, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
     'ua_tta_chunk': [C.POINTER(TtaState), _p, _p, _i32, _i64, _i64, _p, _p, _p, _p],

@@ -30,20 +30,47 @@ class GemmProfiler:
     def __init__(self):
         self.records = []
 
-    def summary(self):
-        flops = sum(r[2] for r in self.records)
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        return dict(launches=len(self.records), flops=flops, ms=ms)
+    def summary(self, kind=None):
+        recs = [r for r in self.records if kind is None or r[3] == kind]
+        flops = sum(r[2] for r in recs)
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        return dict(launches=len(recs), flops=flops, ms=ms)
 
 
 PROFILER = None          # set to a GemmProfiler to time every GEMM launch
 
 
+class SplitW:
+    """A weight matrix (N,K) pre-split into the H32L32 format of ua_gemm_split (include/uniadapter.h),
+    K zero-padded to a multiple of 32, scaled by a per-matrix power of two so that the fp16 'hi'
+    part uses the fp16 range and the 'lo' part is a normal number."""
+
+    def __init__(self, w):
+        N, K = w.shape
+        self.N, self.K = N, _round_up(K, 32)
+        amax = float(w.abs().max())
+        self.scale = float(min(4096.0, 2.0 ** math.floor(math.log2(30000.0 / max(amax, 1e-30)))))
+        w = w.contiguous()
+        self.data = torch.empty(N, self.K, device=w.device, dtype=torch.float32)      # same bytes as fp32
+        lib.call('ua_split_f16', w.data_ptr(), w.stride(0), self.data.data_ptr(), self.K, N, K, self.K, self.scale,
+                 lib.stream_ptr())
+
+
+def _act_scale(bound):
+    """Power-of-two scale for a split activation whose magnitude is bounded by `bound`."""
+    return float(min(16.0, 2.0 ** math.floor(math.log2(30000.0 / max(bound, 1e-30)))))
+
+
 def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgroup_add=None, ldg=0,
-          group_rows=0, act=0, residual=None, ldr=0, pool_out=None, ldp=0, pool_rows=0, alg_flops=None):
-    """C (M,N) = A (M,K) @ W (N,K)^T + epilogue; all tensors already on device, fp32.
+          group_rows=0, act=0, residual=None, ldr=0, pool_out=None, ldp=0, pool_rows=0, alg_flops=None,
+          split_out=None, ld_split=0, split_scale=1.0, a_scale=None):
+    """C (M,N) = A (M,K) @ W (N,K)^T + epilogue; all tensors already on device.
+    W is an fp32 tensor (exact-f32 MFMA kernel, A fp32) or a SplitW (3xf16-split MFMA kernel, A an
+    H32L32 split matrix with scale `a_scale`).  `split_out`: also/only emit the output in split form.
     `alg_flops`: algorithmic FLOPs of the launch when K/N carry zero padding (default 2MNK)."""
     e = GemmEpilogue()
+    e.split_out = split_out.data_ptr() if split_out is not None else None
+    e.ld_split, e.split_scale = ld_split, split_scale
     e.bias = bias.data_ptr() if bias is not None else None
     e.scale = scale.data_ptr() if scale is not None else None
     e.shift = shift.data_ptr() if shift is not None else None
@@ -57,16 +84,27 @@ def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgr
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    lib.call('ua_gemm', A.data_ptr(), lda, W.data_ptr(), W.stride(0), out.data_ptr() if out is not None else None,
-             ldc, M, N, K, C.byref(e), lib.stream_ptr())
+    if isinstance(W, SplitW):
+        lib.call('ua_gemm_split', A.data_ptr(), lda, a_scale, W.data.data_ptr(), W.K, W.scale,
+                 out.data_ptr() if out is not None else None, ldc, M, N, W.K, C.byref(e), lib.stream_ptr())
+        kind = 'split'
+    else:
+        lib.call('ua_gemm', A.data_ptr(), lda, W.data_ptr(), W.stride(0), out.data_ptr() if out is not None else None,
+                 ldc, M, N, K, C.byref(e), lib.stream_ptr())
+        kind = 'f32'
     if prof is not None:
         ev1.record()
-        prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K))
+        prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K, kind))
 
 
-def _ln(x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad):
-    lib.call('ua_layernorm', x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), ldy,
-             rows, cols, cols_pad, lib.stream_ptr())
+def _ln(x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad, split_scale=None):
+    """LayerNorm; with `split_scale` the output is written as an H32L32 split matrix."""
+    if split_scale is None:
+        lib.call('ua_layernorm', x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), ldy,
+                 rows, cols, cols_pad, lib.stream_ptr())
+    else:
+        lib.call('ua_layernorm_split', x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), eps, y.data_ptr(), ldy,
+                 rows, cols, cols_pad, split_scale, lib.stream_ptr())
 
 
 def _round_up(x, m):
@@ -83,7 +121,7 @@ class PointcloudEncoder(nn.Module):
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_group: int, group_size: int, num_heads: int,
                  device=None, prefix: str = 'point_encoder.', ln_eps: float = 1e-6, bn_eps: float = 1e-5,
-                 fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8):
+                 fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8, precision: str = 'f32'):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('uni_adapter_amd.PointcloudEncoder needs a HIP device (MI355X); no CPU path')
@@ -91,6 +129,10 @@ class PointcloudEncoder(nn.Module):
         self.num_group, self.group_size, self.num_heads = int(num_group), int(group_size), int(num_heads)
         self.ln_eps, self.fps_start, self.fps_skip_eps = float(ln_eps), int(fps_start), float(fps_skip_eps)
         self.pe_clouds = int(pe_clouds)
+        if precision not in ('f32', 'split'):
+            raise ValueError("precision must be 'f32' (exact-f32 MFMA) or 'split' (3xf16-split MFMA, fp32-accurate)")
+        self.precision = precision
+        sp = precision == 'split'
         if self.group_size != 64:
             raise NotImplementedError('patch-embed max-pool epilogue is built for group_size 64 (Uni3D)')
         sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
@@ -109,13 +151,16 @@ class PointcloudEncoder(nn.Module):
         self.b1 = d(sd['encoder.first_conv.0.bias'])
         self.bn1_s, self.bn1_t = bn_affine('encoder.first_conv.1')
         self.w2 = d(sd['encoder.first_conv.3.weight'][:, :, 0]); self.b2 = d(sd['encoder.first_conv.3.bias'])
-        w3 = sd['encoder.second_conv.0.weight'][:, :, 0]
         self.c_loc = self.w2.shape[0]                                             # 256
+        w3 = sd['encoder.second_conv.0.weight'][:, :, 0]
         self.w3g = d(w3[:, :self.c_loc]); self.w3l = d(w3[:, self.c_loc:])        # [global | local] halves
         self.b3 = d(sd['encoder.second_conv.0.bias'])
         self.bn2_s, self.bn2_t = bn_affine('encoder.second_conv.1')
         self.w4 = d(sd['encoder.second_conv.3.weight'][:, :, 0]); self.b4 = d(sd['encoder.second_conv.3.bias'])
         self.enc_dim = self.w4.shape[0]
+        self.n3 = self.w3l.shape[0]
+        if sp:                                    # the three big convs go through the split kernel
+            self.w2, self.w3l, self.w4 = SplitW(self.w2), SplitW(self.w3l), SplitW(self.w4)
         # ---- bridges / positional MLP (:175-186) ----
         self.w_e2t = d(sd['encoder2trans.weight']); self.b_e2t = d(sd['encoder2trans.bias'])
         self.trans_dim = self.w_e2t.shape[0]
@@ -149,6 +194,8 @@ class PointcloudEncoder(nn.Module):
             if has('attn.q_bias'):
                 bqkv = bqkv + torch.cat([g('attn.q_bias'), zeros, g('attn.v_bias') if has('attn.v_bias') else zeros], 0)
             b.wqkv, b.bqkv = d(wqkv), d(bqkv)
+            b.ln1_scale = _act_scale(math.sqrt(Cd) * float(b.n1w.abs().max()) + float(b.n1b.abs().max()))
+            b.ln2_scale = _act_scale(math.sqrt(Cd) * float(b.n2w.abs().max()) + float(b.n2b.abs().max()))
             b.an_w, b.an_b = (d(g('attn.norm.weight')), d(g('attn.norm.bias'))) if has('attn.norm.weight') else (None, None)
             b.wproj, b.bproj = d(g('attn.proj.weight')), d(g('attn.proj.bias'))
             b.gamma1 = d(g('gamma_1')) if has('gamma_1') else None
@@ -170,6 +217,9 @@ class PointcloudEncoder(nn.Module):
             b.H, b.Hp = H, Hp
             b.mn_w, b.mn_b = (d(g('mlp.norm.weight')), d(g('mlp.norm.bias'))) if has('mlp.norm.weight') else (None, None)
             b.w2 = d(torch.nn.functional.pad(g('mlp.fc2.weight'), (0, Hp - H))); b.b2 = d(g('mlp.fc2.bias'))
+            b.mn_scale = _act_scale(math.sqrt(H) * float(b.mn_w.abs().max()) + float(b.mn_b.abs().max())) if b.mn_w is not None else 1.0
+            if sp:
+                b.wqkv, b.wproj, b.w1, b.w2 = SplitW(b.wqkv), SplitW(b.wproj), SplitW(b.w1), SplitW(b.w2)
             self.blocks.append(b)
         self.norm = (d(sd['visual.norm.weight']), d(sd['visual.norm.bias'])) if 'visual.norm.weight' in sd else None
         self.fc_norm = (d(sd['visual.fc_norm.weight']), d(sd['visual.fc_norm.bias'])) if 'visual.fc_norm.weight' in sd else None
@@ -188,8 +238,8 @@ class PointcloudEncoder(nn.Module):
         e = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
         ws = dict(
             centers=e(Bc, G, 3), centers4=torch.zeros(Bc * G, 4, device=self.dev), feat=e(Mp, 8),
-            h1=e(Mp, 128), loc=e(Mp, self.c_loc), glob=e(pc * G, self.c_loc), g3=e(pc * G, self.w3g.shape[0]),
-            h3=e(Mp, self.w3l.shape[0]), tok=e(Bc * G, self.enc_dim), tokc=e(Bc * G, Cd), posh=e(Bc * G, 128),
+            h1=e(Mp, 128), loc=e(Mp, self.c_loc), glob=e(pc * G, self.c_loc), g3=e(pc * G, self.n3),
+            h3=e(Mp, self.n3), tok=e(Bc * G, self.enc_dim), tokc=e(Bc * G, Cd), posh=e(Bc * G, 128),
             pos=e(Bc * G, Cd), x=e(rows, Cd), h=e(rows, Cd), qkv=e(rows, 3 * Cd), att=e(rows, Cd),
             hid=e(rows, Hp), hidn=e(rows, Hp), cls=e(Bc, Cd), cls2=e(Bc, Cd), out=e(Bc, self.embed_dim))
         self._ws[Bc] = ws
@@ -209,22 +259,35 @@ class PointcloudEncoder(nn.Module):
         lib.call('ua_fps', pts.data_ptr(), Bc, N, G, self.fps_start, self.fps_skip_eps, None, w['centers'].data_ptr(), st)
         w['centers4'][:, :3].copy_(w['centers'].view(-1, 3))
         # ---- mini-PointNet per chunk of clouds (:145-159) ----
+        sp = self.precision == 'split'
         pc = min(self.pe_clouds, Bc)
         for c0 in range(0, Bc, pc):
             nb = min(pc, Bc - c0)
             Mp, Mg = nb * G * S, nb * G
             lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr(), w['centers'][c0:].data_ptr(),
                      nb, N, G, S, w['feat'].data_ptr(), 8, None, st)
-            _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
-                  alg_flops=2.0 * Mp * 128 * self.in_ch)
-            _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
-                  pool_out=w['glob'], ldp=self.c_loc, pool_rows=64)
-            n3 = self.w3g.shape[0]
-            _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
-            _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
-                  group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
-            _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
-                  pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
+            n3 = self.n3
+            if not sp:
+                _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
+                      alg_flops=2.0 * Mp * 128 * self.in_ch)
+                _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=64)
+                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
+                _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
+                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
+                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
+            else:
+                # same chain; the per-point activations h1 / loc / h3 only ever exist in split form
+                _gemm(w['feat'], 8, self.w1, None, 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
+                      alg_flops=2.0 * Mp * 128 * self.in_ch, split_out=w['h1'], ld_split=128)
+                _gemm(w['h1'], 128, self.w2, None, self.c_loc, Mp, self.c_loc, 128, bias=self.b2, a_scale=1.0,
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=64, split_out=w['loc'], ld_split=self.c_loc)
+                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
+                _gemm(w['loc'], self.c_loc, self.w3l, None, n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
+                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU, a_scale=1.0, split_out=w['h3'], ld_split=n3)
+                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4, a_scale=1.0,
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
         # ---- token assembly (:198-208) ----
         Mg = Bc * G
         _gemm(w['tok'], self.enc_dim, self.w_e2t, w['tokc'], Cd, Mg, Cd, self.enc_dim, bias=self.b_e2t)
@@ -236,26 +299,38 @@ class PointcloudEncoder(nn.Module):
         rows = Mg + Bc
         x = w['x']
         for b in self.blocks:
-            _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
-            _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv)
+            # split mode: every GEMM operand is an H32L32 pair written directly by its producer (LN
+            # kernel) or converted once (attention output); x, qkv and the SwiGLU hidden stay fp32.
+            s1 = b.ln1_scale if sp else None
+            _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)
+            _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv, a_scale=s1)
             lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
-            att = w['att']
+            att, s_att = w['att'], None
             if b.an_w is not None:
-                _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+                s_att = _act_scale(math.sqrt(Cd) * float(b.an_w.abs().max()) + float(b.an_b.abs().max())) if sp else None
+                _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s_att)
                 att = w['h']
-            _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd)
-            _ln(x, Cd, b.n2w, b.n2b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+            elif sp:
+                lib.call('ua_split_f16', att.data_ptr(), Cd, w['h'].data_ptr(), Cd, rows, Cd, Cd, 1.0, st)
+                att, s_att = w['h'], 1.0
+            _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att)
+            s2 = b.ln2_scale if sp else None
+            _ln(x, Cd, b.n2w, b.n2b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s2)
             Hp = b.Hp
             ld_h = w['hid'].stride(0)
             if b.act == ACT_SWIGLU:
-                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, 2 * Hp, Cd, bias=b.b1, act=ACT_SWIGLU, alg_flops=4.0 * rows * b.H * Cd)
+                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, 2 * Hp, Cd, bias=b.b1, act=ACT_SWIGLU, alg_flops=4.0 * rows * b.H * Cd, a_scale=s2)
             else:
-                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, Hp, Cd, bias=b.b1, act=ACT_GELU, alg_flops=2.0 * rows * b.H * Cd)
-            hid = w['hid']
+                _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, Hp, Cd, bias=b.b1, act=ACT_GELU, alg_flops=2.0 * rows * b.H * Cd, a_scale=s2)
+            hid, s_h = w['hid'], None
             if b.mn_w is not None:
-                _ln(w['hid'], ld_h, b.mn_w, b.mn_b, self.ln_eps, w['hidn'], ld_h, rows, b.H, Hp)
+                s_h = b.mn_scale if sp else None
+                _ln(w['hid'], ld_h, b.mn_w, b.mn_b, self.ln_eps, w['hidn'], ld_h, rows, b.H, Hp, split_scale=s_h)
                 hid = w['hidn']
-            _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H)
+            elif sp:
+                lib.call('ua_split_f16', hid.data_ptr(), ld_h, w['hidn'].data_ptr(), ld_h, rows, b.H, Hp, 1.0, st)
+                hid, s_h = w['hidn'], 1.0
+            _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H, a_scale=s_h)
         # ---- head (:219-222) on the CLS rows ----
         cls = x[Mg:]
         cur, nxt = cls, w['cls']
@@ -275,7 +350,7 @@ class PointcloudEncoder(nn.Module):
         """Algorithmic FLOPs of one forward (SURVEY section 8d bookkeeping, reference formulation)."""
         G, S, Cd = self.num_group, self.group_size, self.trans_dim
         T = G + 1
-        f = G * S * 2 * (self.in_ch * 128 + 128 * self.c_loc + (2 * self.c_loc) * self.w3l.shape[0] + self.w3l.shape[0] * self.enc_dim)
+        f = G * S * 2 * (self.in_ch * 128 + 128 * self.c_loc + (2 * self.c_loc) * self.n3 + self.n3 * self.enc_dim)
         f += G * 2 * (self.enc_dim * Cd + 3 * 128 + 128 * Cd)
         for b in self.blocks:
             f += 2 * T * Cd * Cd * 4 + 4 * T * T * Cd
