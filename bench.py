@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 
 
@@ -52,7 +53,8 @@ def parse():
     ap.add_argument('--no-similarity', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=3)
     ap.add_argument('--no-res-learning', action='store_true')
-    ap.add_argument('--precision', choices=['f32', 'split'], default=os.environ.get('UA_GEMM_PRECISION', 'f32'),
+    ap.add_argument('--no-both-modes', dest='both_modes', action='store_false', help='skip the second GEMM mode')
+    ap.add_argument('--precision', choices=['f32', 'split'], default=os.environ.get('UA_GEMM_PRECISION', 'split'),
                     help="GEMM mode: 'f32' exact-f32 MFMA, 'split' 3xf16-split MFMA (fp32-accurate)")
     return ap.parse_args()
 
@@ -162,25 +164,16 @@ def main():
     import uni_adapter_amd  # noqa: F401
     from uni_adapter_amd import point_encoder as PE, synthetic
     from uni_adapter_amd.Uni_Adapter import TtaEngine
-
     cfg = dict(G=512, S=64, heads=16, M=8, res=not a.no_res_learning)
     # real ModelNet40 text bank (K=40, D=1024) ships as fixture data; weights are random-init
     gpath = os.path.join(ROOT, 'tests', 'golden', 'g2_stream_modelnet40.npz')
     text = torch.from_numpy(np.load(gpath)['text']) if os.path.exists(gpath) else synthetic.text_bank(40, 1024)
     sd = synthetic.uni3d_state_dict(0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=a.depth, device=dev)
-    model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
-                                            precision=a.precision)
     n_local, n_global = a.chunk, a.chunk * world
     total_steps = a.warmup + a.steps
     # the whole synthetic stream is resident in HBM before the timed region (same stream on every rank)
     xyz, rgb = synthetic.point_clouds(n_global * total_steps, 1024, seed=42, device=dev)
     noise = torch.randn(xyz.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
-                    chunk=n_global, device=dev)
-
-    def step(i):
-        s = slice(i * n_global, (i + 1) * n_global)
-        return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
 
     def fence():
         torch.cuda.synchronize()
@@ -188,42 +181,77 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    log('model + stream resident; warm-up')
-    for i in range(a.warmup):
-        step(i)
-        torch.cuda.synchronize(); log(f'warm-up step {i} done')
-    prof = PE.GemmProfiler()
-    fence()
-    PE.PROFILER = prof
-    t0 = time.perf_counter()
-    for i in range(a.warmup, total_steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    PE.PROFILER = None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    samples = n_global * a.steps
-    log(f'timed region: {dt:.3f}s for {samples} samples')
-    gsum = prof.summary()
-    tfl = gsum['flops'] / (gsum['ms'] * 1e-3) / 1e12 if gsum['ms'] > 0 else 0.0
+    def run_mode(precision):
+        """W warm-up + K timed steps of the full loop in one GEMM mode; returns the result fields."""
+        model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
+                                                precision=precision)
+        eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
+                        chunk=n_global, device=dev)
+
+        def step(i):
+            s = slice(i * n_global, (i + 1) * n_global)
+            return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
+
+        log(f'[{precision}] model + stream resident; warm-up')
+        for i in range(a.warmup):
+            step(i)
+        prof = PE.GemmProfiler()
+        fence()
+        PE.PROFILER = prof
+        t0 = time.perf_counter()
+        for i in range(a.warmup, total_steps):
+            out = step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        PE.PROFILER = None
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        samples = n_global * a.steps
+        log(f'[{precision}] timed region: {dt:.3f}s for {samples} samples')
+        kinds = {k: prof.summary(k) for k in ('f32', 'split')}
+        dom = max(kinds, key=lambda k: kinds[k]['ms'])
+        g = kinds[dom]
+        tfl = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+        if dom == 'split':
+            # algorithmic (fp32-equivalent) FLOPs; every product costs 3 f16 MFMA products, so the matrix
+            # pipe executes 3x these FLOPs - both fractions are given against the dense f16 MFMA peak
+            roof = {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tfl / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_split_kernel',
+                    'mfma_dtype': 'f16 (3 MFMAs per fp32-accurate product)', 'executed_frac': round(3 * tfl / PEAK_F16_MFMA_TFLOPS, 4),
+                    'vs_f32_mfma_peak': round(tfl / PEAK_FP32_MFMA_TFLOPS, 3)}
+        else:
+            roof = {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tfl / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_f32_mfma_kernel',
+                    'mfma_dtype': 'f32'}
+        roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
+                     'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
+                     'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt, 4)})
+        preds = out[2].clone()
+        del eng, model
+        torch.cuda.empty_cache()
+        return {'value': round(samples / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'roofline': roof}, preds
+
+    main_mode, (res, preds) = a.precision, run_mode(a.precision)
     out = {
         'metric': 'point-clouds/sec (1024 pts), Uni3D-L + MODE-DOTA M=8 test-time stream (ModelNet40-C shaped)',
-        'value': round(samples / dt, 3), 'unit': 'point-clouds/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'value': res['value'], 'unit': 'point-clouds/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if main_mode == 'f32' else 'f32 (GEMM products as 3 x f16-split MFMA, f32 accumulate; fp32-GEMM accuracy)',
+        'data': 'synthetic',
         'config': {'workload': 'Uni3D-L encoder x2 forwards/sample + MODE-DOTA cache step (K=40, M=8, D=1024, residual learning '
                                + ('on' if cfg['res'] else 'off') + ') on synthetic 1024-pt clouds; BASELINE.json configs[1]',
                    'samples_per_rank_per_step': n_local, 'global_samples_per_step': n_global, 'encoder_depth': a.depth,
+                   'gemm_mode': main_mode,
                    'parallelism': f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step'},
-        'roofline': {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(tfl / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_f32_mfma_kernel',
-                     'launches': gsum['launches'], 'flops_per_launch_avg': gsum['flops'] / max(1, gsum['launches']),
-                     'ms_per_launch_avg': round(gsum['ms'] / max(1, gsum['launches']), 5),
-                     'gemm_share_of_step_time': round(gsum['ms'] * 1e-3 / dt, 4)},
+        'roofline': res['roofline'],
     }
+    if a.both_modes:
+        other = 'f32' if main_mode == 'split' else 'split'
+        res2, preds2 = run_mode(other)
+        out['other_gemm_mode'] = {'gemm_mode': other, 'value': res2['value'], 'ms_per_step': res2['ms_per_step'], 'roofline': res2['roofline'],
+                                  'last_step_predictions_identical': bool(torch.equal(preds, preds2))}
     if rank == 0 and not a.no_similarity:
         out['similarity'] = similarity_roofline(dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

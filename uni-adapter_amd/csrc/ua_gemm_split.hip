@@ -10,10 +10,10 @@
 //
 // Tiling: 256x256 output tile per 512-thread workgroup (8 waves as 2x4, each 128x64 = 4x2 MFMA
 // blocks, 128 accumulator VGPRs), K consumed in 32-column slabs.  A slab row of one operand is one
-// 128-byte line of the H32L32 matrix (64 B hi | 64 B lo) and lands in a 144-byte LDS row (the
-// 16-byte pad makes the ds_read_b128 fragment reads conflict-free).  Two LDS buffers of
-// 2 x 256 x 144 B = 144 KiB: one workgroup per CU, two waves per SIMD.  Per slab a wave issues
-// 24 ds_read_b128 and 48 MFMAs (1536 matrix-pipe cycles), the workgroup stages 64 KiB.
+// 128-byte line of the H32L32 matrix (64 B hi | 64 B lo), copied global->LDS by LDS-DMA into an
+// XOR-swizzled image of unpadded 128-byte rows (see split_mainloop).  Two LDS buffers of
+// 2 x 256 x 128 B = 128 KiB: one workgroup per CU, two waves per SIMD.  Per slab a wave issues
+// 8 LDS-DMA copies, 24 ds_read_b128 and 48 MFMAs (1536 matrix-pipe cycles); the workgroup stages 64 KiB.
 // Full row panels are balanced over the XCDs; the thin CLS-row tiles come last (1/8 round).
 #include "ua_gemm_common.h"
 
@@ -24,8 +24,9 @@ using ua::f16x8;
 using ua::EpiArgs;
 
 constexpr int SBM = 256, SBN = 256, SBK = 32;
-constexpr int S_ROW = 144;                           // LDS bytes per slab row
-constexpr int S_TILE = SBM * S_ROW;                  // 36,864 B per operand tile
+constexpr int S_ROW = 128;                           // LDS bytes per slab row: 8 chunks of 16 B (4 hi | 4 lo)
+constexpr int S_TILE = SBM * S_ROW;                  // 32,768 B per operand tile
+constexpr int S_LDS = 8 * 64 * ua::EP_LD * 4;        // 139,264 B: max(main loop 131,072, epilogue staging)
 
 struct SplitArgs {
     const unsigned char* A; const unsigned char* W;
@@ -35,56 +36,64 @@ struct SplitArgs {
     int tiles_n, n_tiles;
 };
 
-__device__ __forceinline__ uint4 ld_row_clamped(const unsigned char* base, long long ld, int row, int nrows, int k0, int c) {
-    const int rc = min(row, nrows - 1);
-    return *reinterpret_cast<const uint4*>(base + ((size_t)rc * ld + k0) * 4 + c * 16);
-}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// Staging is LDS-DMA (global_load_lds_dwordx4): every wave-instruction copies 64 x 16 B from per-lane
+// global addresses to 1 KiB of CONTIGUOUS LDS (wave-uniform base + lane*16) - no staging VGPRs, no
+// ds_write.  The LDS image therefore has unpadded 128-byte rows; bank conflicts of the fragment
+// reads are removed by an XOR swizzle applied on the SOURCE side: LDS chunk position p of row r
+// holds global chunk p ^ ((r>>1)&7), and the reads apply the same involution.  (16 lanes of a
+// ds_read_b128 group read 16 distinct rows r; (r&1, (r>>1)&7 ^ c) are 16 distinct 16-byte slots of the
+// 256-byte bank row.)  Rows beyond M / N are clamped to the last row: they only feed accumulators
+// that are never stored, so no zero-fill is needed (K is a multiple of 32).
 template <bool FULL>
 __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn, int li, int lh,
                                                const bool (&on)[4][2], f32x16 (&acc)[4][2]) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];   // [2 buffers][A tile | W tile]
-    uint4 ra[4], rw[4];
-    auto fetch = [&](int k0) {
+    const int lane = tid & 63;
+    const unsigned char* ga[4];
+    const unsigned char* gw[4];
+    int ldo[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 512 * i, row = f >> 3, c = f & 7;
-            ra[i] = ld_row_clamped(g.A, g.lda, m0 + row, g.M, k0, c);
-            rw[i] = ld_row_clamped(g.W, g.ldw, n0 + row, g.N, k0, c);
-        }
-    };
-    auto stash = [&](int buf) {
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 512 * i, row = f >> 3, p = f & 7, c = p ^ ((row >> 1) & 7);
+        ga[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda * 4 + c * 16;
+        gw[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw * 4 + c * 16;
+        ldo[i] = (f - lane) * 16;                              // wave-uniform LDS byte offset of this copy
+    }
+    auto issue = [&](int buf, int k0) {
         unsigned char* a = slds + buf * 2 * S_TILE;
-        unsigned char* w = a + S_TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = tid + 512 * i, row = f >> 3, c = f & 7;
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(a + row * S_ROW + c * 16) = (FULL || (m0 + row) < g.M) ? ra[i] : z;
-            *reinterpret_cast<uint4*>(w + row * S_ROW + c * 16) = (FULL || (n0 + row) < g.N) ? rw[i] : z;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + (size_t)k0 * 4), (lds_ptr_t)(a + ldo[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[i] + (size_t)k0 * 4), (lds_ptr_t)(a + S_TILE + ldo[i]), 16, 0, 0);
         }
     };
+    // fragment read offsets: lane (row li of a 32-row block, k-half lh), k16 step s: hi chunk 2s+lh, lo chunk 4+2s+lh
     const int nk = g.K / SBK;
-    fetch(0);
-    stash(0);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        fetch(min(t + 1, nk - 1) * SBK);                       // unconditional (last one re-reads slab nk-1)
-        const unsigned char* a = slds + buf * 2 * S_TILE + (wm * 128 + li) * S_ROW + lh * 16;
-        const unsigned char* w = slds + buf * 2 * S_TILE + S_TILE + (wn * 64 + li) * S_ROW + lh * 16;
+        if (t + 1 < nk) issue(buf ^ 1, (t + 1) * SBK);          // in flight behind this slab's MFMAs
+        const unsigned char* a = slds + buf * 2 * S_TILE + (wm * 128 + li) * S_ROW;
+        const unsigned char* w = slds + buf * 2 * S_TILE + S_TILE + (wn * 64 + li) * S_ROW;
+        const int sw = (li >> 1) & 7;                          // row-dependent swizzle ((row>>1)&7; block offsets are multiples of 32)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                          // two k16 steps per slab
+            const int ph = ((2 * s + lh) ^ sw) * 16, pl = ((4 + 2 * s + lh) ^ sw) * 16;
             f16x8 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + s * 32);
-                al[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + 64 + s * 32);
+                ah[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + ph);
+                al[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + pl);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                wh[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + s * 32);
-                wl[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + 64 + s * 32);
+                wh[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + ph);
+                wl[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + pl);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -96,24 +105,32 @@ __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
                     }
         }
-        stash(buf ^ 1);
+        // the DMA of slab t+1 must have landed (this wave's part) before anyone reads it, and every
+        // wave must be done reading slab t before slab t+2 overwrites its buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
-    // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by blockIdx; the FULL row
-    // panels are chunked so that every XCD owns a contiguous band (A-panel reuse in its L2) and an
-    // equal number of full tiles; the tiles of a partial last row panel (here: the 32 CLS rows, 1/8
-    // of the MFMA work each) come last in block order, one per XCD, so they add 1/8 of a round
-    // instead of making XCDs 0..r-1 run a second full round.
+    // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by blockIdx.  The tiles of a
+    // partial last row panel (here the 32 CLS rows: almost no MFMA work but a full K walk) take the
+    // FIRST blockIdx values, so they overlap with the first round instead of forming a tail; the
+    // full tiles follow, chunked so that every XCD (blockIdx % 8) owns a contiguous band of row
+    // panels (A-panel reuse in its L2) and all XCDs get the same number of full tiles (+-1).
     const int bid = blockIdx.x;
     const int n_full = (g.M / SBM) * g.tiles_n;
-    int tile = bid;
-    if (bid < n_full) {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = n_full >> 3, r = n_full & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int n_thin = g.n_tiles - n_full;
+    int tile;
+    if (bid < n_thin) {
+        tile = n_full + bid;
+    } else {
+        const int xcd = bid & 7, t8 = n_thin & 7;
+        auto first = [&](int x) { return n_thin + ((x - t8 + 8) & 7); };            // first full-tile block on XCD x
+        auto count = [&](int x) { const int f = first(x); return f >= g.n_tiles ? 0 : (g.n_tiles - f + 7) >> 3; };
+        int start = 0;
+        for (int x = 0; x < xcd; ++x) start += count(x);
+        tile = start + ((bid - first(xcd)) >> 3);
     }
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
     const int m0 = tm * SBM, n0 = tn * SBN;
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     if (full) split_mainloop<true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
     else      split_mainloop<false>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
 
-    // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B <= 147,456 B)
+    // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B = 139,264 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
     float* stage = reinterpret_cast<float*>(slds) + wid * 64 * ua::EP_LD;
 #pragma unroll
@@ -200,7 +217,7 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     g.ep.acc_scale = 1.0f / (a_scale * w_scale);
     const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
-    const size_t lds = (size_t)4 * S_TILE;                            // 147,456 B
+    const size_t lds = (size_t)S_LDS;                                 // 139,264 B
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel),
