@@ -214,6 +214,14 @@ int ua_layernorm_split(const float* x, int64_t ldx, const float* w, const float*
 int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
                  int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
 
+/* Same attention with fp32-accurate products on the f16 matrix cores: qkv is an H32L32 split matrix
+ * (rows, 3*H*hd) with scale qkv_scale (as emitted by ua_gemm_split's split_out), the result is
+ * written as fp32 (out, optional) and/or as an H32L32 split matrix (out_split, optional) for the
+ * proj GEMM.  Softmax statistics and all accumulation are fp32.                                   */
+int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+                       void* out_split, int64_t ldos, float out_scale,
+                       int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
+
 /* Token assembly (models/point_encoder.py:198-208): x[b*G+g] = tok[b*G+g] + pos[b*G+g];
  * x[Bc*G+b] = cls_token + cls_pos.                                                             */
 int ua_assemble_tokens(const float* tok, const float* pos, const float* cls_token,

@@ -520,3 +520,26 @@ def test_layernorm_split_output(ua):
     ref = torch.nn.functional.layer_norm(x[:, :cols].double(), (cols,), w.double(), b.double(), 1e-6)
     assert (rec[:, :cols] - ref).abs().max().item() < 2e-5
     assert torch.equal(rec[:, cols:], torch.zeros(rows, pad - cols, dtype=torch.float64))
+
+
+@pytest.mark.parametrize('Bc,G,H', [(2, 512, 16), (1, 128, 2), (3, 256, 4)])
+def test_attention_split(ua, Bc, G, H):
+    """Split-precision attention: H32L32 qkv in, fp32 and split outputs, vs fp64 softmax attention -
+    same tolerance as the exact-f32 kernel."""
+    g = torch.Generator().manual_seed(Bc * G + H)
+    hd, Cd = 64, H * 64
+    rows = Bc * G + Bc
+    qkv = torch.randn(rows, 3 * Cd, generator=g) * 1.5
+    qs = _split(ua, dev(qkv), 3 * Cd, 1.0)
+    out = torch.zeros(rows, Cd, device='cuda'); outs = torch.zeros(rows, Cd, device='cuda')
+    ua.call('ua_attention_split', qs.data_ptr(), 3 * Cd, 1.0, ua.ptr(out), Cd, outs.data_ptr(), Cd, 4.0, Bc, G, H, hd, ua.stream_ptr())
+    o = out.cpu().double()
+    raw = outs.cpu().view(torch.float16).reshape(rows, Cd // 32, 2, 32)
+    osplit = (raw[:, :, 0].double() + raw[:, :, 1].double()).reshape(rows, Cd) / 4.0
+    for b in range(Bc):
+        r = torch.cat([torch.arange(b * G, (b + 1) * G), torch.tensor([Bc * G + b])])
+        x = qkv[r].double()
+        q, k, v = [t.reshape(G + 1, H, hd).transpose(0, 1) for t in x.split(Cd, -1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(0, 1).reshape(G + 1, Cd)
+        assert (o[r] - ref).abs().max().item() < 2e-5
+        assert (osplit[r] - ref).abs().max().item() < 2e-5

@@ -79,6 +79,20 @@ def attn():
         print(f'Bc={Bc:3d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s  frac {fl / med / 1e9 / 157.3:.3f}')
 
 
+def attn_split():
+    print('== ua_attention_split (3 x f16 MFMA)')
+    for Bc in (2, 8, 32):
+        G, H, hd = 512, 16, 64
+        rows = Bc * G + Bc; Cd = H * hd
+        qkv = torch.randn(rows, 3 * Cd, device='cuda'); qs = torch.empty_like(qkv); out = torch.empty(rows, Cd, device='cuda')
+        st = lib.stream_ptr()
+        lib.call('ua_split_f16', qkv.data_ptr(), 3 * Cd, qs.data_ptr(), 3 * Cd, rows, 3 * Cd, 3 * Cd, 1.0, st)
+        fn = lambda: lib.call('ua_attention_split', qs.data_ptr(), 3 * Cd, 1.0, None, 0, out.data_ptr(), Cd, 1.0, Bc, G, H, hd, st)
+        med, mn = timeit(fn)
+        fl = 4.0 * (G + 1) ** 2 * Cd * Bc
+        print(f'Bc={Bc:3d}  {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s-equiv')
+
+
 def group():
     print('== ua_fps / ua_knn_group')
     for B in (2, 32):

@@ -32,5 +32,15 @@ A = torch.randn(Mr, Kk, device='cuda'); W = torch.randn(N, Kk, device='cuda') / 
 e = GemmEpilogue()
 for _ in range(3):
     lib.call('ua_gemm', A.data_ptr(), Kk, W.data_ptr(), Kk, Cc.data_ptr(), N, Mr, N, Kk, C.byref(e), st)
+# split GEMM of the same shape + split attention
+As = torch.empty(Mr, Kk, device='cuda'); Ws = torch.empty(N, Kk, device='cuda')
+lib.call('ua_split_f16', A.data_ptr(), Kk, As.data_ptr(), Kk, Mr, Kk, Kk, 1.0, st)
+lib.call('ua_split_f16', W.data_ptr(), Kk, Ws.data_ptr(), Kk, N, Kk, Kk, 1024.0, st)
+for _ in range(3):
+    lib.call('ua_gemm_split', As.data_ptr(), Kk, 1.0, Ws.data_ptr(), Kk, 1024.0, Cc.data_ptr(), N, Mr, N, Kk, C.byref(e), st)
+qs = torch.empty(Mr, N, device='cuda'); lib.call('ua_split_f16', Cc.data_ptr(), N, qs.data_ptr(), N, Mr, N, N, 1.0, st)
+ao = torch.empty(Mr, 1024, device='cuda')
+for _ in range(3):
+    lib.call('ua_attention_split', qs.data_ptr(), N, 1.0, None, 0, ao.data_ptr(), 1024, 1.0, 32, 512, 16, 64, st)
 torch.cuda.synchronize()
 print('pmc probe done: similarity algorithmic bytes', 2 * K * M * D * 4, 'fused', 4 * K * M * D * 4, 'gemm A+W+C bytes', 4 * (Mr * Kk + N * Kk + Mr * N))

@@ -1,0 +1,226 @@
+// Multi-head self-attention with fp32-accurate products on the f16 matrix cores (3-term split,
+// fp32 accumulate, fp32 softmax) - the ua_gemm_split companion of ua_attention.hip.
+//
+// Reference semantics: timm EvaAttention without rope (models/point_encoder.py:217-218;
+// extract_attention.py:121-177): softmax(q k^T * hd^-0.5) v per head.
+//
+// Operands arrive in the H32L32 split format straight from the qkv GEMM epilogue (no fp32 qkv is
+// ever written) and the result is written in split form for the proj GEMM.  Per head the 64
+// features of q/k/v are two 32-column groups = 256 contiguous bytes [hi 0-31 | lo 0-31 | hi 32-63 |
+// lo 32-63] of a token row.
+//
+// Mapping (as ua_attention.hip): workgroup = (cloud, head, 128 queries), 4 wavefronts x 32 queries;
+// 32-key K/V tiles double-buffered in LDS.  S^T = K Q^T with v_mfma_f32_32x32x16_f16 (query on the
+// lane, keys in the 16 accumulator registers -> in-lane softmax row reductions); each product is
+// hi*hi + hi*lo + lo*hi.  P is split in registers (p in [0,1]) and is directly the B operand of
+// O^T += V^T P^T; the A operand needs V^T, so V is transposed while it is staged into LDS
+// ([feature][key] rows), which turns each fragment into two 8-byte reads.
+// Per key tile a wave issues 24 MFMAs (768 matrix-pipe cycles) instead of 64 f32 MFMAs (4096).
+#include "ua_gemm_common.h"
+
+namespace {
+
+using ua::f32x16;
+using ua::f16x8;
+using ua::f16x4;
+
+constexpr int HD = 64, KT = 32;
+constexpr int KROW = 272;              // LDS bytes per key row (256 + 16 pad: conflict-free ds_read_b128)
+constexpr int VROW = 136;              // LDS bytes per feature row of V^T: 32 keys hi (64 B) | lo (64 B) + 8 pad
+
+__global__ void __launch_bounds__(256, 2)
+attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, float c_scale, float v_inv_scale,
+                       float* __restrict__ out, long long ldo, unsigned char* __restrict__ out_split, long long ldos,
+                       float out_scale, int Bc, int G, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_k[2][KT * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char s_v[2][HD * VROW];
+    const int C = H * HD;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int n_qb_patch = G / 128;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t row_bytes = (size_t)ldqkv * 4;
+    const size_t q_off = (size_t)(h * HD) * 4, k_off = (size_t)(C + h * HD) * 4, v_off = (size_t)(2 * C + h * HD) * 4;
+
+    const bool cls_block = qb >= n_qb_patch;
+    const int q_local = wid * 32 + li;
+    long long q_row; bool q_valid;
+    if (!cls_block) { q_row = (long long)b * G + qb * 128 + q_local; q_valid = true; }
+    else            { q_row = (long long)Bc * G + b; q_valid = (q_local == 0); }
+    const bool wave_active = !cls_block || wid == 0;
+
+    // Q fragments: k16 step s covers features 16s..16s+15; lane half lh holds 8 of them
+    f16x8 qh[4], ql[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned char* p = qkv + (size_t)q_row * row_bytes + q_off + (s >> 1) * 128 + (16 * (s & 1) + 8 * lh) * 2;
+        if (q_valid) { qh[s] = *reinterpret_cast<const f16x8*>(p); ql[s] = *reinterpret_cast<const f16x8*>(p + 64); }
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qh[s][j] = (_Float16)0.f; ql[s][j] = (_Float16)0.f; }
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: 256 threads x 2 chunks of 16 B cover 32 keys x 256 B for K and for V
+    const int n_pt = G / KT, n_tiles = n_pt + 1;
+    uint4 rk[2], rv[2];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + 256 * p, key = f >> 4, c = f & 15;
+            long long row; bool ok;
+            if (t < n_pt) { row = (long long)b * G + t * KT + key; ok = true; }
+            else          { row = (long long)Bc * G + b; ok = (key == 0); }
+            rk[p] = make_uint4(0u, 0u, 0u, 0u); rv[p] = rk[p];
+            if (ok) {
+                const unsigned char* base = qkv + (size_t)row * row_bytes + c * 16;
+                rk[p] = *reinterpret_cast<const uint4*>(base + k_off);
+                rv[p] = *reinterpret_cast<const uint4*>(base + v_off);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + 256 * p, key = f >> 4, c = f & 15;
+            *reinterpret_cast<uint4*>(&s_k[buf][key * KROW + c * 16]) = rk[p];
+            // transpose V: chunk c holds 8 halves of features d0..d0+7 (hi if (c&7)<4 else lo)
+            const int d0 = (c >> 3) * 32 + (c & 3) * 8;
+            const int part = ((c & 7) >= 4) ? 64 : 0;
+            const unsigned short* hv = reinterpret_cast<const unsigned short*>(&rv[p]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<unsigned short*>(&s_v[buf][(d0 + j) * VROW + part + key * 2]) = hv[j];
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) fetch(t + 1);
+        if (wave_active) {
+            // ---- S^T[key][q] = sum_d K[key][d] Q[q][d] (3 f16 MFMAs per k16 step) ----
+            f32x16 sacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+            const unsigned char* kp = &s_k[buf][li * KROW];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int o = (s >> 1) * 128 + (16 * (s & 1) + 8 * lh) * 2;
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kp + o);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + o + 64);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+            }
+            const int n_valid = (t < n_pt) ? KT : 1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                sacc[e] = (key < n_valid) ? sacc[e] * c_scale : -INFINITY;        // c_scale = hd^-0.5 / s^2 (power of two)
+            }
+            // ---- online softmax, fp32 (row = lane's query; other half of the row is lane^32) ----
+            float mt = sacc[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sacc[e]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = expf(m_run - m_new);
+            float psum = 0.f;
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = expf(sacc[e] - m_new);
+                psum += p;
+                const _Float16 hi = (_Float16)p;
+                ph[e >> 3][e & 7] = hi;
+                pl[e >> 3][e & 7] = (_Float16)(p - (float)hi);
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+            // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; slot i of half lh <-> key (i&3)+8(i>>2)+4lh+16ks ----
+            const unsigned char* vp = &s_v[buf][li * VROW + (4 * lh) * 2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned char* r = vp + db * 32 * VROW + ks * 32;
+                    f16x8 vh, vl;
+                    const f16x4 a0 = *reinterpret_cast<const f16x4*>(r), a1 = *reinterpret_cast<const f16x4*>(r + 16);
+                    const f16x4 b0 = *reinterpret_cast<const f16x4*>(r + 64), b1 = *reinterpret_cast<const f16x4*>(r + 80);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    if (db == 0) {
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[ks], o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[ks], o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[ks], o0, 0, 0, 0);
+                    } else {
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[ks], o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[ks], o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[ks], o1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (t + 1 < n_tiles) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = v_inv_scale / l_tot;
+    if (q_valid) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int d = 8 * e4 + 4 * lh;
+            const float4 v0 = make_float4(o0[4 * e4] * inv, o0[4 * e4 + 1] * inv, o0[4 * e4 + 2] * inv, o0[4 * e4 + 3] * inv);
+            const float4 v1 = make_float4(o1[4 * e4] * inv, o1[4 * e4 + 1] * inv, o1[4 * e4 + 2] * inv, o1[4 * e4 + 3] * inv);
+            if (out) {
+                float* orow = out + q_row * ldo + h * HD;
+                *reinterpret_cast<float4*>(orow + d) = v0;
+                *reinterpret_cast<float4*>(orow + 32 + d) = v1;
+            }
+            if (out_split) {
+                unsigned char* srow = out_split + (size_t)q_row * ldos * 4;
+                f16x4 hi, lo;
+                ua::split4(v0, out_scale, hi, lo);
+                unsigned char* q0 = srow + ua::split_col_off(h * HD + d);
+                *reinterpret_cast<f16x4*>(q0) = hi; *reinterpret_cast<f16x4*>(q0 + 64) = lo;
+                ua::split4(v1, out_scale, hi, lo);
+                unsigned char* q1 = srow + ua::split_col_off(h * HD + 32 + d);
+                *reinterpret_cast<f16x4*>(q1) = hi; *reinterpret_cast<f16x4*>(q1 + 64) = lo;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+                                  void* out_split, int64_t ldos, float out_scale,
+                                  int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+    UA_CHECK_PTR(qkv); UA_CHECK_ALIGN16(qkv);
+    if (!out && !out_split) return UA_EINVAL;
+    if (Bc <= 0 || G <= 0 || H <= 0 || !(qkv_scale > 0.f)) return UA_EINVAL;
+    if (hd != HD || G % 128 != 0) return UA_EUNSUPPORTED;
+    if (ldqkv % 32 || ldqkv < 3LL * H * HD) return UA_EALIGN;
+    if (out && (ldo % 4 || ldo < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out) & 15))) return UA_EALIGN;
+    if (out_split && (ldos % 32 || ldos < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out_split) & 15) || !(out_scale > 0.f))) return UA_EALIGN;
+    if (H > 65535 || Bc > 65535) return UA_EUNSUPPORTED;
+    dim3 grid(G / 128 + 1, H, Bc);
+    const float c_scale = 0.125f / (qkv_scale * qkv_scale);           // hd^-0.5 for hd = 64, exact
+    hipLaunchKernelGGL(attention_split_kernel, grid, dim3(256), 0, ua::as_stream(stream),
+                       reinterpret_cast<const unsigned char*>(qkv), (long long)ldqkv, c_scale, 1.0f / qkv_scale,
+                       out, (long long)ldo, reinterpret_cast<unsigned char*>(out_split), (long long)ldos, out_scale, Bc, G, H);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}

@@ -67,6 +67,7 @@ SIGNATURES = {
     'ua_split_f16': [_p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p],
     'ua_gemm_split': [_p, _i64, _f, _p, _i64, _f, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    'ua_attention_split': [_p, _i64, _f, _p, _i64, _p, _i64, _f, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
     'ua_tta_chunk': [C.POINTER(TtaState), _p, _p, _i32, _i64, _i64, _p, _p, _p, _p],
 }

@@ -303,16 +303,27 @@ class PointcloudEncoder(nn.Module):
             # kernel) or converted once (attention output); x, qkv and the SwiGLU hidden stay fp32.
             s1 = b.ln1_scale if sp else None
             _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)
-            _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv, a_scale=s1)
-            lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
-            att, s_att = w['att'], None
-            if b.an_w is not None:
-                s_att = _act_scale(math.sqrt(Cd) * float(b.an_w.abs().max()) + float(b.an_b.abs().max())) if sp else None
-                _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s_att)
-                att = w['h']
-            elif sp:
-                lib.call('ua_split_f16', att.data_ptr(), Cd, w['h'].data_ptr(), Cd, rows, Cd, Cd, 1.0, st)
-                att, s_att = w['h'], 1.0
+            if not sp:
+                _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv)
+                lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
+                att, s_att = w['att'], None
+                if b.an_w is not None:
+                    _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+                    att = w['h']
+            else:
+                # q/k/v only ever exist as a split matrix; attention writes its result in split form too
+                _gemm(w['h'], Cd, b.wqkv, None, 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv, a_scale=s1,
+                      split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0)
+                if b.an_w is None:
+                    lib.call('ua_attention_split', w['qkv'].data_ptr(), 3 * Cd, 1.0, None, 0, w['h'].data_ptr(), Cd, 1.0,
+                             Bc, G, Hh, Cd // Hh, st)
+                    att, s_att = w['h'], 1.0
+                else:
+                    lib.call('ua_attention_split', w['qkv'].data_ptr(), 3 * Cd, 1.0, w['att'].data_ptr(), Cd, None, 0, 1.0,
+                             Bc, G, Hh, Cd // Hh, st)
+                    s_att = _act_scale(math.sqrt(Cd) * float(b.an_w.abs().max()) + float(b.an_b.abs().max()))
+                    _ln(w['att'], Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s_att)
+                    att = w['h']
             _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att)
             s2 = b.ln2_scale if sp else None
             _ln(x, Cd, b.n2w, b.n2b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s2)
