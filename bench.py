@@ -53,6 +53,8 @@ def parse():
     ap.add_argument('--no-similarity', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=3)
     ap.add_argument('--no-res-learning', action='store_true')
+    ap.add_argument('--no-overlap', dest='overlap', action='store_false',
+                    help='run the in-order cache replay on the encoder stream instead of a second stream')
     ap.add_argument('--no-both-modes', dest='both_modes', action='store_false', help='skip the second GEMM mode')
     ap.add_argument('--precision', choices=['f32', 'split'], default=os.environ.get('UA_GEMM_PRECISION', 'split'),
                     help="GEMM mode: 'f32' exact-f32 MFMA, 'split' 3xf16-split MFMA (fp32-accurate)")
@@ -186,7 +188,7 @@ def main():
         model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
                                                 precision=precision)
         eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
-                        chunk=n_global, device=dev)
+                        chunk=n_global, device=dev, overlap=a.overlap)
 
         def step(i):
             s = slice(i * n_global, (i + 1) * n_global)
@@ -244,6 +246,7 @@ def main():
                                + ('on' if cfg['res'] else 'off') + ') on synthetic 1024-pt clouds; BASELINE.json configs[1]',
                    'samples_per_rank_per_step': n_local, 'global_samples_per_step': n_global, 'encoder_depth': a.depth,
                    'gemm_mode': main_mode,
+                   'replay_overlap': bool(a.overlap),
                    'parallelism': f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step'},
         'roofline': res['roofline'],
     }

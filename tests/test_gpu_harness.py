@@ -173,3 +173,25 @@ def test_composite_entry_equals_per_kernel_calls(golden_dir):
                     eng.residuals.res.cpu().clone(), eng.residuals.step, eng.mode_dota_model.mu.cpu().clone(), eng.accuracy()))
     for a, b in zip(res[0], res[1]):
         assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b)
+
+
+def test_replay_overlap_gives_identical_results(golden_dir):
+    """overlap=True (cache replay on a second stream while the next chunk is encoded) must not
+    change a single bit of the outputs."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd import synthetic
+    sd = synthetic.uni3d_state_dict(3, trans_dim=128, embed_dim=256, depth=2)
+    text = synthetic.text_bank(12, 256, 1)
+    xyz, rgb = synthetic.point_clouds(12, 1024, 5)
+    noise = torch.randn(12, 1024, 3, generator=torch.Generator().manual_seed(2))
+    tgt = torch.arange(12, dtype=torch.int32) % 12
+    outs = []
+    for overlap in (False, True):
+        model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, precision='split')
+        eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 4, chunk=4, overlap=overlap)
+        res = [eng.process_chunk(xyz[s:s + 4], rgb[s:s + 4], tgt[s:s + 4], noise[s:s + 4]) for s in range(0, 12, 4)]
+        eng.synchronize()
+        outs.append((torch.cat([r[0] for r in res]).cpu(), torch.cat([r[1] for r in res]).cpu(), eng.accuracy(), eng.residuals.res.cpu().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and torch.equal(outs[0][3], outs[1][3])

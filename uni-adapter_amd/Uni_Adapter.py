@@ -110,9 +110,14 @@ class TtaEngine:
     test_zeroshot_3d_core (the reference rebuilds all state per corruption, Uni_Adapter.py:336-352)."""
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
-                 log_alignment_every=0, dist_group=None, composite=True):
+                 log_alignment_every=0, dist_group=None, composite=True, overlap=False):
         self.model = model
         self.composite = bool(composite) and not log_alignment_every
+        # overlap=True: the in-order cache replay of chunk c runs on a second HIP stream while the
+        # caller's stream already encodes chunk c+1 (the encoder does not depend on the cache state).
+        # Results are complete after `synchronize()` (or the next `accuracy()`); same arithmetic.
+        self.overlap = bool(overlap) and self.composite
+        self.replay_stream = torch.cuda.Stream(device=device) if self.overlap else None
         self.dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.text = text_features.detach().to(self.dev, torch.float32).contiguous()          # (K,D)
         self.K, self.D = self.text.shape
@@ -237,24 +242,42 @@ class TtaEngine:
             # one host call enqueues the whole in-order replay of the chunk (csrc/ua_tta.hip)
             import ctypes
             feats = feats.contiguous()
-            lib.call('ua_tta_chunk', ctypes.byref(self._state), lib.ptr(feats), lib.ptr(tgt, torch.int32) if tgt is not None else None,
-                     n, self.i, self.residuals.step if self.res_learning else 0, lib.ptr(final),
-                     lib.ptr(ranks, torch.int32) if tgt is not None else None, lib.ptr(preds, torch.int32), lib.stream_ptr())
+            main = torch.cuda.current_stream()
+            rs = self.replay_stream if self.overlap else main
+            if self.overlap:
+                rs.wait_stream(main)                       # features (and everything allocated above) are ready
+                for t in (feats, final, ranks, preds, tgt):
+                    if t is not None:
+                        t.record_stream(rs)
+            with torch.cuda.stream(rs):
+                lib.call('ua_tta_chunk', ctypes.byref(self._state), lib.ptr(feats), lib.ptr(tgt, torch.int32) if tgt is not None else None,
+                         n, self.i, self.residuals.step if self.res_learning else 0, lib.ptr(final),
+                         lib.ptr(ranks, torch.int32) if tgt is not None else None, lib.ptr(preds, torch.int32), rs.cuda_stream)
+                if tgt is not None:                                                          # utils/utils.py:154-167
+                    self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
+                    self.count += n
             if self.res_learning:
                 self.residuals.step += RES_STEPS * (n - (1 if self.i == 0 else 0))
             self.i += n
             self.mode_dota_model.t += 2 * n
-        else:
-            for j in range(n):
-                self.cache_step(feats[j, 0:1], feats[j, 1:2], tgt[j:j + 1] if tgt is not None else None,
-                                final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
+            return final, ranks, preds
+        for j in range(n):
+            self.cache_step(feats[j, 0:1], feats[j, 1:2], tgt[j:j + 1] if tgt is not None else None,
+                            final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
         if tgt is not None:                                                                  # utils/utils.py:154-167
             self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
             self.count += n
         return final, ranks, preds
 
+    def synchronize(self):
+        """Wait for all enqueued work of this engine (both streams)."""
+        if self.replay_stream is not None:
+            self.replay_stream.synchronize()
+        torch.cuda.current_stream().synchronize()
+
     def accuracy(self):
         """{'acc1','acc3','acc5'} in percent over everything processed so far (host sync)."""
+        self.synchronize()
         c = self.correct.tolist()
         d = max(1, self.count)
         return {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}
@@ -284,7 +307,8 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
                                 '--precomputed-text-features')
     chunk = int(getattr(args, 'chunk_size', 16))
     eng = TtaEngine(model, text_features, dota_cfg, args.mode_M, res_learning=getattr(args, 'res_learning', True),
-                    chunk=chunk, device=dev, log_alignment_every=getattr(args, 'print_freq', 0))
+                    chunk=chunk, device=dev, log_alignment_every=getattr(args, 'log_alignment_every', 0),
+                    overlap=getattr(args, 'overlap_replay', True))
     logging.info(f"Initialized MODE-DOTA model with M={args.mode_M}.")
     noise_fn = getattr(args, 'aug_noise', None)
     start_event, end_event = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -309,6 +333,8 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
             if len(buf_pc) == chunk:
                 flush()
     flush()
+    if eng.replay_stream is not None:
+        torch.cuda.current_stream().wait_stream(eng.replay_stream)
     end_event.record()
     torch.cuda.synchronize()
     acc = eng.accuracy()

@@ -13,8 +13,9 @@
 // 32-key K/V tiles double-buffered in LDS.  S^T = K Q^T with v_mfma_f32_32x32x16_f16 (query on the
 // lane, keys in the 16 accumulator registers -> in-lane softmax row reductions); each product is
 // hi*hi + hi*lo + lo*hi.  P is split in registers (p in [0,1]) and is directly the B operand of
-// O^T += V^T P^T; the A operand needs V^T, so V is transposed while it is staged into LDS
-// ([feature][key] rows), which turns each fragment into two 8-byte reads.
+// O^T += V^T P^T; the A operand needs V^T: V is staged row-major exactly like K and transposed on
+// the way out of LDS by ds_read_b64_tr_b16 (each 16-lane group reads a 4-key x 16-feature block
+// and every lane receives the 4 keys of its feature), two transposed reads per fragment.
 // Per key tile a wave issues 24 MFMAs (768 matrix-pipe cycles) instead of 64 f32 MFMAs (4096).
 #include "ua_gemm_common.h"
 
@@ -26,14 +27,15 @@ using ua::f16x4;
 
 constexpr int HD = 64, KT = 32;
 constexpr int KROW = 272;              // LDS bytes per key row (256 + 16 pad: conflict-free ds_read_b128)
-constexpr int VROW = 136;              // LDS bytes per feature row of V^T: 32 keys hi (64 B) | lo (64 B) + 8 pad
+constexpr int VROW = 320;              // LDS bytes per key row of V (256 + 64: rows 16 banks apart -> conflict-free ds_read_b64_tr_b16)
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
 __global__ void __launch_bounds__(256, 2)
 attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, float c_scale, float v_inv_scale,
                        float* __restrict__ out, long long ldo, unsigned char* __restrict__ out_split, long long ldos,
                        float out_scale, int Bc, int G, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][KT * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned char s_v[2][HD * VROW];
+    __shared__ __attribute__((aligned(16))) unsigned char s_v[2][KT * VROW];
     const int C = H * HD;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int n_qb_patch = G / 128;
@@ -89,13 +91,7 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
         for (int p = 0; p < 2; ++p) {
             const int f = tid + 256 * p, key = f >> 4, c = f & 15;
             *reinterpret_cast<uint4*>(&s_k[buf][key * KROW + c * 16]) = rk[p];
-            // transpose V: chunk c holds 8 halves of features d0..d0+7 (hi if (c&7)<4 else lo)
-            const int d0 = (c >> 3) * 32 + (c & 3) * 8;
-            const int part = ((c & 7) >= 4) ? 64 : 0;
-            const unsigned short* hv = reinterpret_cast<const unsigned short*>(&rv[p]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *reinterpret_cast<unsigned short*>(&s_v[buf][(d0 + j) * VROW + part + key * 2]) = hv[j];
+            *reinterpret_cast<uint4*>(&s_v[buf][key * VROW + c * 16]) = rv[p];
         }
     };
 
@@ -148,17 +144,27 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
 #pragma unroll
             for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
             // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; slot i of half lh <-> key (i&3)+8(i>>2)+4lh+16ks ----
-            const unsigned char* vp = &s_v[buf][li * VROW + (4 * lh) * 2];
+            // transposed-read addressing: 16-lane group Gq = lane>>4 handles features 16*(Gq&1).. of the
+            // 32-feature block and keys 4*(Gq>>1)+{0..3} (+16ks, +8); lane 4q+p of the group supplies row q,
+            // features 4p..4p+3; it receives feature (lane&15) of the 4 keys = the MFMA A-operand slots.
+            const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+            const unsigned char* vp = &s_v[buf][(4 * (gq >> 1) + tq) * VROW + (16 * (gq & 1) + 4 * tp) * 2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const unsigned char* r = vp + db * 32 * VROW + ks * 32;
+                    const unsigned char* r = vp + (16 * ks) * VROW + db * 128;
+                    typedef __attribute__((address_space(3))) s16x4* lp_t;
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 8 * VROW));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 64));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 8 * VROW + 64));
                     f16x8 vh, vl;
-                    const f16x4 a0 = *reinterpret_cast<const f16x4*>(r), a1 = *reinterpret_cast<const f16x4*>(r + 16);
-                    const f16x4 b0 = *reinterpret_cast<const f16x4*>(r + 64), b1 = *reinterpret_cast<const f16x4*>(r + 80);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    for (int j = 0; j < 4; ++j) {
+                        vh[j] = __builtin_bit_cast(_Float16, a0[j]); vh[4 + j] = __builtin_bit_cast(_Float16, a1[j]);
+                        vl[j] = __builtin_bit_cast(_Float16, b0[j]); vl[4 + j] = __builtin_bit_cast(_Float16, b1[j]);
+                    }
                     if (db == 0) {
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[ks], o0, 0, 0, 0);
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[ks], o0, 0, 0, 0);

@@ -16,6 +16,7 @@
 // 8 LDS-DMA copies, 24 ds_read_b128 and 48 MFMAs (1536 matrix-pipe cycles); the workgroup stages 64 KiB.
 // Full row panels are balanced over the XCDs; the thin CLS-row tiles come last (1/8 round).
 #include "ua_gemm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct SplitArgs {
     int M, N, K;
     EpiArgs ep;
     int tiles_n, n_tiles;
+    int stagger;                                     // waves 4-7 run half a slab behind waves 0-3
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -47,7 +49,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // ds_read_b128 group read 16 distinct rows r; (r&1, (r>>1)&7 ^ c) are 16 distinct 16-byte slots of the
 // 256-byte bank row.)  Rows beyond M / N are clamped to the last row: they only feed accumulators
 // that are never stored, so no zero-fill is needed (K is a multiple of 32).
-template <bool FULL>
+template <bool FULL, bool LATE>
 __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn, int li, int lh,
                                                const bool (&on)[4][2], f32x16 (&acc)[4][2]) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];   // [2 buffers][A tile | W tile]
@@ -71,45 +73,61 @@ __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n
         }
     };
     // fragment read offsets: lane (row li of a 32-row block, k-half lh), k16 step s: hi chunk 2s+lh, lo chunk 4+2s+lh
+    const int sw = (li >> 1) & 7;                              // row-dependent swizzle ((row>>1)&7; block offsets are multiples of 32)
+    f16x8 ah[4], al[4], wh[2], wl[2];
+    auto read_frags = [&](int buf, int s) {
+        const unsigned char* a = slds + buf * 2 * S_TILE + (wm * 128 + li) * S_ROW;
+        const unsigned char* w = slds + buf * 2 * S_TILE + S_TILE + (wn * 64 + li) * S_ROW;
+        const int ph = ((2 * s + lh) ^ sw) * 16, pl = ((4 + 2 * s + lh) ^ sw) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + ph);
+            al[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + pl);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wh[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + ph);
+            wl[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + pl);
+        }
+    };
+    auto mfma_block = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (FULL || on[i][j]) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+                }
+    };
     const int nk = g.K / SBK;
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // Between two barriers every wave does 2 fragment reads + 2 x 24 MFMAs.  !LATE (waves 0-3):
+    // [R(t,0) M(t,0) R(t,1) M(t,1)].  LATE (waves 4-7, the second wave of every SIMD) runs half a slab
+    // behind: [M(t-1,1) R(t,0) M(t,0) R(t,1)] - its operands for the first MFMA block are already in
+    // registers when the barrier opens, so the matrix pipe has work while the early wave waits for LDS,
+    // and the early wave's last MFMA block covers the late wave's reads (the two waves of a SIMD no
+    // longer hit their LDS/barrier waits together).
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         if (t + 1 < nk) issue(buf ^ 1, (t + 1) * SBK);          // in flight behind this slab's MFMAs
-        const unsigned char* a = slds + buf * 2 * S_TILE + (wm * 128 + li) * S_ROW;
-        const unsigned char* w = slds + buf * 2 * S_TILE + S_TILE + (wn * 64 + li) * S_ROW;
-        const int sw = (li >> 1) & 7;                          // row-dependent swizzle ((row>>1)&7; block offsets are multiples of 32)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {                          // two k16 steps per slab
-            const int ph = ((2 * s + lh) ^ sw) * 16, pl = ((4 + 2 * s + lh) ^ sw) * 16;
-            f16x8 ah[4], al[4], wh[2], wl[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + ph);
-                al[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * S_ROW + pl);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                wh[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + ph);
-                wl[j] = *reinterpret_cast<const f16x8*>(w + j * 32 * S_ROW + pl);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (FULL || on[i][j]) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
-                    }
+        if (!LATE) {
+            read_frags(buf, 0); mfma_block();
+            read_frags(buf, 1); mfma_block();
+        } else {
+            if (t > 0) mfma_block();                           // M(t-1, 1), operands read before the barrier
+            read_frags(buf, 0); mfma_block();
+            read_frags(buf, 1);
         }
         // the DMA of slab t+1 must have landed (this wave's part) before anyone reads it, and every
         // wave must be done reading slab t before slab t+2 overwrites its buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (LATE) mfma_block();                                    // M(nk-1, 1)
 }
 
 __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
@@ -154,8 +172,11 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             on[i][j] = ((m0 + swm * 128 + i * 32) < g.M) && ((n0 + swn * 64 + j * 32) < g.N);
-    if (full) split_mainloop<true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
-    else      split_mainloop<false>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+    const bool late = g.stagger && __builtin_amdgcn_readfirstlane(wid) >= 4;
+    if (full) { if (late) split_mainloop<true, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+                else      split_mainloop<true, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
+    else      { if (late) split_mainloop<false, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+                else      split_mainloop<false, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
 
     // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B = 139,264 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
@@ -217,6 +238,8 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     g.ep.acc_scale = 1.0f / (a_scale * w_scale);
     const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
+    static const int stagger = [] { const char* e = getenv("UA_SPLIT_STAGGER"); return e ? atoi(e) : 1; }();
+    g.stagger = stagger;
     const size_t lds = (size_t)S_LDS;                                 // 139,264 B
     static bool attr_set = false;
     if (!attr_set) {
