@@ -159,12 +159,10 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 8 * VROW));
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 64));
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(r + 8 * VROW + 64));
-                    f16x8 vh, vl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        vh[j] = __builtin_bit_cast(_Float16, a0[j]); vh[4 + j] = __builtin_bit_cast(_Float16, a1[j]);
-                        vl[j] = __builtin_bit_cast(_Float16, b0[j]); vl[4 + j] = __builtin_bit_cast(_Float16, b1[j]);
-                    }
+                    // (whole-vector concatenation + one bit-cast: element-wise bit_casts of the v4i16
+                    //  results were mis-lowered by hipcc 7.2 into duplicated registers)
+                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
                     if (db == 0) {
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[ks], o0, 0, 0, 0);
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[ks], o0, 0, 0, 0);
