@@ -47,7 +47,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--chunk', type=int, default=16, help='samples per rank per step')
+    ap.add_argument('--chunk', type=int, default=31,
+                    help='samples per rank per step (31 -> 62 clouds: 256x256 GEMM tile counts land just under multiples of 256 CUs)')
     ap.add_argument('--depth', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-similarity', action='store_true')
@@ -156,11 +157,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device('cuda', local_rank % ndev)                         # (rehearsals may put several ranks on one GPU)
+    torch.cuda.set_device(dev)
+    backend = os.environ.get('UA_DIST_BACKEND', 'nccl')                   # 'nccl' = RCCL over xGMI; 'gloo' only for rehearsals
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)'
 
     import uni_adapter_amd  # noqa: F401
@@ -207,7 +213,7 @@ def main():
         dt = time.perf_counter() - t0
         PE.PROFILER = None
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         samples = n_global * a.steps

@@ -32,8 +32,15 @@ def gather_features(local, n, rank, world, group=None):
     per = (n + world - 1) // world
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    torch.distributed.all_gather(parts, pad, group=group)
-    stacked = torch.stack(parts, 0)                       # (W, per, ...)
+    if pad.is_cuda and torch.distributed.get_backend(group) == 'gloo':
+        # rehearsal path (several ranks sharing one GPU, gloo): stage through host memory
+        host = pad.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        torch.distributed.all_gather(parts, host, group=group)
+        stacked = torch.stack(parts, 0).to(pad.device)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        torch.distributed.all_gather(parts, pad, group=group)   # RCCL over xGMI on a multi-GPU node
+        stacked = torch.stack(parts, 0)                   # (W, per, ...)
     j = torch.arange(n, device=local.device)
     return stacked[j % world, j // world]
