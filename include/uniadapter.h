@@ -146,7 +146,8 @@ int ua_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int32_t start, flo
 
 /* knn_point + Group.forward (models/point_encoder.py:17-49, 99-127): the S nearest points of
  * every centre under the expanded-form distance -2c.p+|c|^2+|p|^2, gathered as
- * [xyz - centre, rgb].  feat (B*G*S, ldf) with ldf >= 6 (columns 6..ldf-1 are zero-filled);
+ * [xyz - centre, rgb] (rgb == NULL: xyz-only groups of models/ulip/pointbert/dvae.py:152-181, the
+ * colour columns are zero).  feat (B*G*S, ldf) with ldf >= 6 (columns 6..ldf-1 are zero-filled);
  * idx (B,G,S) int32 optional (ascending index order inside a group).  N <= 4096, S <= 256.     */
 int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
                  int32_t B, int32_t N, int32_t G, int32_t S,
@@ -158,7 +159,7 @@ int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
  *   act: 0 none | 1 ReLU | 2 GELU(erf) | 3 SwiGLU (columns come in blocks of 32 gate / 32 up:
  *        out[:, j] = silu(gate)*up, N_out = N/2; timm SwiGLU of EvaBlock)
  *   v += residual[m, n]
- *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64)
+ *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64 or 32)
  *   split_out (optional): the same output as an H32L32 split-precision matrix (see ua_split_f16)  */
 typedef struct {
     const float* bias;
@@ -254,6 +255,12 @@ typedef struct {
 int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int32_t* targets, int32_t n,
                  int64_t sample_index0, int64_t adam_step0, float* final_logits,
                  int32_t* ranks, int32_t* preds, void* stream);
+
+/* PointBERT / ULIP-2 variant (models/ulip/pointbert/point_encoder.py:95-98,173-192):
+ * ua_add_pos: x += pos before every block (patch rows get pos[b*G+g], CLS rows cls_pos).
+ * ua_cls_max_concat: out (Bc, 2C) = [x_cls | max over the G patch tokens] (:190).                */
+int ua_add_pos(float* x, const float* pos, const float* cls_pos, int32_t Bc, int32_t G, int32_t C, void* stream);
+int ua_cls_max_concat(const float* x, float* out, int32_t Bc, int32_t G, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

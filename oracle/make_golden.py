@@ -326,6 +326,26 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'g7_fps.npz'), xyz=xyz[:1].numpy(), start=np.int64(start),
                         centers=pts.numpy())
     print('g7 start', start)
+    # ---- G8: ULIP-2 PointBERT (models/ulip/pointbert/point_encoder.py + dvae.py + ulip_model.py) ----
+    dv_ns = {'torch': torch, 'nn': nn, 'F': F, 'fps': given_fps}
+    _exec_defs(os.path.join(REF, 'models', 'ulip', 'pointbert', 'dvae.py'), ['knn_point', 'square_distance', 'Group', 'Encoder'], dv_ns)
+    pt_ns = {'torch': torch, 'nn': nn, 'F': F, 'DropPath': nn.Identity, 'Group': dv_ns['Group'], 'Encoder': dv_ns['Encoder']}
+    _exec_defs(os.path.join(REF, 'models', 'ulip', 'pointbert', 'point_encoder.py'),
+               ['Mlp', 'Attention', 'Block', 'TransformerEncoder', 'PointTransformer'], pt_ns)
+    uargs = types.SimpleNamespace(pc_feat_dim=768, pc_depth=2, drop_path_rate=0.0, num_head=6, group_size=32, num_group=128, encoder_dim=256)
+    usd = O.make_ulip_state_dict(9, trans_dim=384, depth=2)
+    ptm = pt_ns['PointTransformer'](uargs)
+    missing = ptm.load_state_dict({k[len('point_encoder.'):]: v for k, v in usd.items() if k.startswith('point_encoder.')}, strict=True)
+    ptm.eval()
+    uxyz = xyz[:, :, :]
+    ucidx = O.fps(uxyz, 128, start=3, skip_origin_eps=-1.0)
+    box['centers'] = uxyz[torch.arange(2)[:, None], ucidx]
+    with torch.no_grad():
+        ucat = ptm(uxyz)
+        uemb = ucat @ usd['pc_projection']                                   # ulip_model.py:15-18
+    np.savez_compressed(os.path.join(OUT, 'g8_ulip.npz'), xyz=uxyz.numpy(), center_idx=ucidx.numpy(), weights_seed=np.int64(9),
+                        concat=ucat.numpy(), embed=uemb.numpy())
+    print('g8 ulip', uemb.shape, uemb[0, :3])
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

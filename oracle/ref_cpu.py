@@ -486,6 +486,81 @@ def make_uni3d_state_dict(seed: int, trans_dim: int, embed_dim: int, enc_dim: in
 
 
 # ======================================================================================
+# A4b  ULIP-2 PointBERT encoder variant
+# ======================================================================================
+def ulip_encode_pc(xyz: torch.Tensor, sd: Dict[str, torch.Tensor], num_group: int, group_size: int, n_heads: int,
+                   center_idx: Optional[torch.Tensor] = None, fps_start: int = 0, ln_eps: float = 1e-5,
+                   prefix: str = 'point_encoder.', return_concat: bool = False):
+    """models/ulip/ulip_model.py:15-18 + models/ulip/pointbert/point_encoder.py:173-192 (+ dvae.py
+    Group :152-181 / Encoder :184-215).  xyz (B,N,3) -> pc_embed (B, embed).  Differences to the
+    Uni3D path: xyz-only groups (3 channels), group size 32, fused qkv without bias, GELU MLP,
+    nn.LayerNorm eps 1e-5, the positional embedding is re-added before EVERY block (:95-98),
+    output = cat[cls, max over patch tokens] @ pc_projection.  Pinned by tests/golden/g8_ulip.npz."""
+    P = prefix
+    B = xyz.shape[0]
+    if center_idx is None:
+        center_idx = fps(xyz, num_group, start=fps_start, skip_origin_eps=-1.0)
+    ar = torch.arange(B)[:, None]
+    center = xyz[ar, center_idx]
+    idx = knn_point(group_size, xyz, center)
+    nb = xyz[ar[:, :, None], idx] - center[:, :, None, :]
+    tok = patch_encoder(nb, sd, P + 'encoder.')
+    tok = tok @ sd[P + 'reduce_dim.weight'].t() + sd[P + 'reduce_dim.bias']
+    pos = F.gelu(center @ sd[P + 'pos_embed.0.weight'].t() + sd[P + 'pos_embed.0.bias'])
+    pos = pos @ sd[P + 'pos_embed.2.weight'].t() + sd[P + 'pos_embed.2.bias']
+    x = torch.cat([sd[P + 'cls_token'].expand(B, -1, -1), tok], 1)
+    pos = torch.cat([sd[P + 'cls_pos'].expand(B, -1, -1), pos], 1)
+    n_blocks = 1 + max(int(k.split('.')[3]) for k in sd if k.startswith(P + 'blocks.blocks.'))
+    for i in range(n_blocks):
+        x = eva_block(x + pos, sd, f'{P}blocks.blocks.{i}.', n_heads, ln_eps)       # same pre-LN block arithmetic
+    x = _ln(x, sd[P + 'norm.weight'], sd[P + 'norm.bias'], ln_eps)
+    cat = torch.cat([x[:, 0], x[:, 1:].max(1)[0]], -1)
+    out = cat @ sd['pc_projection']
+    return (out, cat) if return_concat else out
+
+
+def make_ulip_state_dict(seed: int, trans_dim: int = 384, depth: int = 12, enc_dim: int = 256, embed: int = 512,
+                         dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights in the ULIP-2 PointBERT key layout (PointTransformer + pc_projection)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, sc=0.02: (torch.randn(*s, generator=g) * sc).to(dtype)
+    P = 'point_encoder.'
+    C = trans_dim
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, co, ci, bias=True):
+        sd[P + name + '.weight'] = rn(co, ci, sc=1 / math.sqrt(ci))
+        if bias:
+            sd[P + name + '.bias'] = rn(co)
+
+    def conv(name, co, ci):
+        sd[P + name + '.weight'] = rn(co, ci, 1, sc=1 / math.sqrt(ci)); sd[P + name + '.bias'] = rn(co)
+
+    def bn(name, c):
+        sd[P + name + '.weight'] = (1 + 0.1 * torch.randn(c, generator=g)).to(dtype)
+        sd[P + name + '.bias'] = rn(c, sc=0.1)
+        sd[P + name + '.running_mean'] = rn(c, sc=0.1)
+        sd[P + name + '.running_var'] = (1 + 0.2 * torch.rand(c, generator=g)).to(dtype)
+
+    def ln(name, c):
+        sd[P + name + '.weight'] = (1 + 0.05 * torch.randn(c, generator=g)).to(dtype); sd[P + name + '.bias'] = rn(c, sc=0.05)
+
+    conv('encoder.first_conv.0', 128, 3); bn('encoder.first_conv.1', 128); conv('encoder.first_conv.3', 256, 128)
+    conv('encoder.second_conv.0', 512, 512); bn('encoder.second_conv.1', 512); conv('encoder.second_conv.3', enc_dim, 512)
+    lin('reduce_dim', C, enc_dim)
+    sd[P + 'cls_token'] = rn(1, 1, C); sd[P + 'cls_pos'] = rn(1, 1, C, sc=0.1)
+    lin('pos_embed.0', 128, 3); lin('pos_embed.2', C, 128)
+    for i in range(depth):
+        b = f'blocks.blocks.{i}.'
+        ln(b + 'norm1', C); ln(b + 'norm2', C)
+        lin(b + 'attn.qkv', 3 * C, C, bias=False); lin(b + 'attn.proj', C, C)
+        lin(b + 'mlp.fc1', 4 * C, C); lin(b + 'mlp.fc2', C, 4 * C)
+    ln('norm', C)
+    sd['pc_projection'] = rn(2 * C, embed, sc=1 / math.sqrt(2 * C))
+    return sd
+
+
+# ======================================================================================
 # A14  per-sample loop (cache part; encoder outputs are inputs)
 # ======================================================================================
 @dataclass

@@ -88,3 +88,54 @@ def test_split_mode_tracks_f32_mode_full_depth():
     print('1-cos', (1 - cos).max().item(), 'max |d logit|', dl)
     assert (1 - cos).max().item() < 1e-10
     assert dl < 1e-3
+
+
+# ---------------------------------------------------------------- ULIP-2 PointBERT variant (section 8 A4b)
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', name))
+
+
+@pytest.mark.parametrize('precision', ['f32', 'split'])
+def test_ulip_encoder_against_reference_fixture(precision):
+    """tests/golden/g8_ulip.npz holds the reference PointTransformer's own output (2 blocks, real
+    widths) on seeded weights; the HIP encoder must agree with it within fp32 noise."""
+    from uni_adapter_amd.point_encoder import create_ulip_from_state_dict
+    g = _golden('g8_ulip.npz')
+    sd = O.make_ulip_state_dict(int(g['weights_seed']), trans_dim=384, depth=2)
+    model = create_ulip_from_state_dict(sd, num_group=128, group_size=32, num_heads=6, precision=precision, fps_start=3)
+    xyz = torch.from_numpy(g['xyz'])
+    out = model(xyz.cuda())
+    ref = torch.from_numpy(g['embed'])
+    sd64 = {k: v.double() for k, v in sd.items()}
+    truth = O.ulip_encode_pc(xyz.double(), sd64, 128, 32, 6, center_idx=torch.from_numpy(g['center_idx']).long())
+    base = (ref.double() - truth).abs().max().item()
+    err = (out.cpu().double() - truth).abs().max().item()
+    scale = truth.abs().max().item()
+    assert err <= max(5 * base, 2e-5 * scale), (err, base, scale)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize('precision', ['f32', 'split'])
+def test_ulip_encoder_full_depth_and_logits_wrapper(precision):
+    """ULIP-2 shape (384 wide, 12 blocks, G=512, S=32, 8192->first 1024 points not needed: N=1024 here)
+    end to end through get_logits_wrapper(vlm3d='ulip') vs the oracle."""
+    import types
+    from uni_adapter_amd.point_encoder import create_ulip_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import get_logits_wrapper
+    from uni_adapter_amd import synthetic
+    sd = synthetic.ulip_state_dict(5, depth=12)
+    pc = _clouds(3, 2048, 9)
+    model = create_ulip_from_state_dict(sd, num_group=512, group_size=32, num_heads=6, precision=precision)
+    out = model(pc[:, :, :3].contiguous().cuda())
+    sdo = {k: v for k, v in sd.items()}
+    ref = O.ulip_encode_pc(pc[:, :, :3], sdo, 512, 32, 6)
+    cos = torch.nn.functional.cosine_similarity(out.cpu().double(), ref.double(), dim=1)
+    assert (1 - cos).max().item() < 1e-8
+    assert (out.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    text = synthetic.text_bank(40, 512, seed=2)
+    args = types.SimpleNamespace(vlm3d='ulip')
+    fh, z, ent, p, pred = get_logits_wrapper(args, model, pc[:1].cuda(), text.t().contiguous().cuda())
+    rz = 100.0 * torch.nn.functional.normalize(ref[:1], dim=1) @ text.t()
+    assert (z.cpu() - rz).abs().max().item() < 1e-3
+    assert pred == int(rz.argmax())

@@ -543,3 +543,58 @@ def test_attention_split(ua, Bc, G, H):
         ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(0, 1).reshape(G + 1, Cd)
         assert (o[r] - ref).abs().max().item() < 2e-5
         assert (osplit[r] - ref).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------ ULIP-2 PointBERT helpers (section 8 A4b)
+def test_gemm_pool_rows_32_both_kernels(ua):
+    """group_size 32 (ULIP): the max-pool / rowgroup epilogues work on 32-row groups."""
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 512, 192, 64
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / 8; b = torch.randn(N, generator=g)
+    rga = torch.randn(M // 32, N, generator=g)
+    ref = torch.relu(A.double() @ W.double().T + b.double() + rga.double().repeat_interleave(32, 0))
+    pool = torch.empty(M // 32, N, device='cuda')
+    Cd = _gemm(ua, dev(A), dev(W), M, N, K, bias=dev(b), rowgroup_add=dev(rga), ldg=N, group_rows=32, act=1,
+               pool_out=pool, ldp=N, pool_rows=32)
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+    assert (pool.cpu().double() - ref.reshape(M // 32, 32, N).max(1)[0]).abs().max().item() < 5e-5
+    from uni_adapter_amd.lib import GemmEpilogue
+    As, Ws = _split(ua, dev(A)), _split(ua, dev(W), scale=256.0)
+    e = GemmEpilogue(); keep = [dev(b), dev(rga)]
+    e.bias, e.rowgroup_add = [t.data_ptr() for t in keep]; e.ldg = N; e.group_rows = 32; e.act = 1
+    pool2 = torch.empty(M // 32, N, device='cuda'); e.pool_out = pool2.data_ptr(); e.ldp = N; e.pool_rows = 32
+    ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, None, N, M, N, K, C.byref(e), ua.stream_ptr())
+    assert (pool2.cpu().double() - ref.reshape(M // 32, 32, N).max(1)[0]).abs().max().item() < 5e-5
+    # a pool size other than 32 | 64 is rejected, not silently mis-pooled
+    e.pool_rows = 16
+    with pytest.raises(RuntimeError):
+        ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, None, N, M, N, K, C.byref(e), ua.stream_ptr())
+
+
+def test_knn_group_xyz_only(ua, golden_dir):
+    """rgb == NULL: colour columns are written as zeros (dvae.py Group has no colour)."""
+    g = _load(golden_dir, 'g5_group.npz')
+    xyz, cidx = _t(g['xyz']), _t(g['center_idx'])
+    B, N, _ = xyz.shape; G = cidx.shape[1]; S = 32
+    centers = xyz[torch.arange(B)[:, None], cidx]
+    f0 = torch.full((B * G * S, 8), 7.0, device='cuda'); i0 = torch.empty(B, G, S, dtype=torch.int32, device='cuda')
+    f1 = torch.full((B * G * S, 8), 7.0, device='cuda'); i1 = torch.empty(B, G, S, dtype=torch.int32, device='cuda')
+    ua.call('ua_knn_group', ua.ptr(dev(xyz)), None, ua.ptr(dev(centers)), B, N, G, S, ua.ptr(f0), 8, ua.ptr(i0, torch.int32), ua.stream_ptr())
+    ua.call('ua_knn_group', ua.ptr(dev(xyz)), ua.ptr(dev(torch.zeros_like(xyz))), ua.ptr(dev(centers)), B, N, G, S, ua.ptr(f1), 8,
+            ua.ptr(i1, torch.int32), ua.stream_ptr())
+    assert torch.equal(f0, f1) and torch.equal(i0, i1)
+    assert torch.equal(f0[:, 3:], torch.zeros_like(f0[:, 3:]))
+
+
+def test_add_pos_and_cls_max_concat(ua):
+    g = torch.Generator().manual_seed(12)
+    Bc, G, Cd = 3, 128, 384
+    x = torch.randn(Bc * G + Bc, Cd, generator=g); pos = torch.randn(Bc * G, Cd, generator=g); cp = torch.randn(Cd, generator=g)
+    xd = dev(x).clone()
+    ua.call('ua_add_pos', ua.ptr(xd), ua.ptr(dev(pos)), ua.ptr(dev(cp)), Bc, G, Cd, ua.stream_ptr())
+    want = torch.cat([x[:Bc * G] + pos, x[Bc * G:] + cp], 0)            # token rows: patches first, CLS rows last
+    assert torch.equal(xd.cpu(), want)
+    out = torch.empty(Bc, 2 * Cd, device='cuda')
+    ua.call('ua_cls_max_concat', ua.ptr(xd), ua.ptr(out), Bc, G, Cd, ua.stream_ptr())
+    ref = torch.cat([want[Bc * G:], want[:Bc * G].reshape(Bc, G, Cd).max(1)[0]], 1)
+    assert torch.equal(out.cpu(), ref)

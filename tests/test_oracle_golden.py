@@ -174,3 +174,16 @@ def test_properties():
     perm = torch.tensor([2, 0, 3, 1])                   # predict is invariant to mode order
     st2 = O.GmmState(st.mu[:, perm], st.var[:, perm], st.pi[:, perm], st.c[:, perm], st.class_counts, st.epsilon)
     np.testing.assert_allclose(O.gmm_predict(st, x).numpy(), O.gmm_predict(st2, x).numpy(), atol=2e-3)
+
+
+def test_g8_ulip_pointbert_encoder(golden_dir):
+    """Oracle restatement of the ULIP-2 PointBERT forward vs the reference PointTransformer's output."""
+    g = _load(golden_dir, 'g8_ulip.npz')
+    sd = O.make_ulip_state_dict(int(g['weights_seed']), trans_dim=384, depth=2)
+    xyz = torch.from_numpy(g['xyz'])
+    # fps restatement reproduces the stored centres (misc.py:40-60 flavour, no origin skip)
+    cidx = O.fps(xyz, 128, start=3, skip_origin_eps=-1.0)
+    assert np.array_equal(cidx.numpy(), g['center_idx'])
+    out, cat = O.ulip_encode_pc(xyz, sd, 128, 32, 6, center_idx=cidx, return_concat=True)
+    assert np.abs(cat.numpy() - g['concat']).max() < 2e-5
+    assert np.abs(out.numpy() - g['embed']).max() < 2e-5

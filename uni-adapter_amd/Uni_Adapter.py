@@ -40,11 +40,15 @@ def softmax_entropy(x, enable_softmax=True, temperature=1.0):
 
 
 def get_logits_wrapper(args, model, feature, clip_weights):
-    """Uni_Adapter.py:53-75 for vlm3d == 'uni3d', batch 1.  `clip_weights` is (D,K) as in the
-    reference.  Returns (pc_features, logits, loss, prob_map, pred:int)."""
-    if getattr(args, 'vlm3d', 'uni3d') != 'uni3d':
-        raise NotImplementedError('only --vlm3d uni3d is wired end-to-end (as in the reference, SURVEY section 0)')
-    feat = model.encode_pc(feature)
+    """Uni_Adapter.py:53-75 for vlm3d in {'uni3d', 'ulip'}, batch 1.  `clip_weights` is (D,K) as in
+    the reference.  Returns (pc_features, logits, loss, prob_map, pred:int)."""
+    vlm = getattr(args, 'vlm3d', 'uni3d')
+    if vlm == 'uni3d':
+        feat = model.encode_pc(feature)                       # :54-57
+    elif vlm == 'ulip':
+        feat = model(feature[:, :, :3].contiguous())          # :58-62 (xyz only)
+    else:
+        raise NotImplementedError("--vlm3d openshape is not built (SURVEY section 8 row F1)")
     if feat.shape[0] != 1:
         raise ValueError('batch size must be 1 (reference defect 6)')
     text = clip_weights.t().contiguous()

@@ -35,7 +35,7 @@ struct EpiArgs {
     int act;                       // 0 none, 1 relu, 2 gelu(erf), 3 swiglu
     const float* residual; long long ldr;
     float* C; long long ldc;
-    float* pool; long long ldp;
+    float* pool; long long ldp; int pool_rows;   // 64 (Uni3D groups) or 32 (PointBERT groups)
     unsigned char* Cs; long long ldcs; float cs_scale;     // optional H32L32 copy of the output
 };
 
@@ -80,7 +80,9 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
     const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);
     const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
     const float as = g.acc_scale;
-    float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
+    float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
+    const bool pool32 = g.pool_rows == 32;
 #pragma unroll 4
     for (int p = 0; p < 16; ++p) {
         const int r = p * 4 + lr, m = mbase + r;
@@ -118,7 +120,8 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
                 *reinterpret_cast<f16x4*>(q) = hi;
                 *reinterpret_cast<f16x4*>(q + 64) = lo;
             }
-            pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w);
+            if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
+            else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
         }
     }
     if (g.pool) {                                                    // max over this wave's 64 rows
@@ -127,10 +130,23 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
             pm.x = fmaxf(pm.x, __shfl_xor(pm.x, o)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, o));
             pm.z = fmaxf(pm.z, __shfl_xor(pm.z, o)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, o));
         }
+        if (pool32) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                pm2.x = fmaxf(pm2.x, __shfl_xor(pm2.x, o)); pm2.y = fmaxf(pm2.y, __shfl_xor(pm2.y, o));
+                pm2.z = fmaxf(pm2.z, __shfl_xor(pm2.z, o)); pm2.w = fmaxf(pm2.w, __shfl_xor(pm2.w, o));
+            }
+        }
+        auto put = [&](float* q, const float4& v) {
+            if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = v;
+            else { if (nout0 < n_out) q[0] = v.x; if (nout0 + 1 < n_out) q[1] = v.y; if (nout0 + 2 < n_out) q[2] = v.z; }
+        };
         if (lr == 0 && mbase < g.M) {
-            float* q = g.pool + (size_t)(mbase / 64) * g.ldp + nout0;
-            if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = pm;
-            else { if (nout0 < n_out) q[0] = pm.x; if (nout0 + 1 < n_out) q[1] = pm.y; if (nout0 + 2 < n_out) q[2] = pm.z; }
+            if (!pool32) put(g.pool + (size_t)(mbase / 64) * g.ldp + nout0, pm);
+            else {
+                put(g.pool + (size_t)(mbase / 32) * g.ldp + nout0, pm);
+                if (mbase + 32 < g.M) put(g.pool + (size_t)(mbase / 32 + 1) * g.ldp + nout0, pm2);
+            }
         }
     }
 }
@@ -143,11 +159,11 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
         e.bias = ep->bias; e.scale = ep->scale; e.shift = ep->shift;
         e.rga = ep->rowgroup_add; e.ldg = ep->ldg; e.group_rows = ep->group_rows;
         e.act = ep->act; e.residual = ep->residual; e.ldr = ep->ldr;
-        e.pool = ep->pool_out; e.ldp = ep->ldp;
+        e.pool = ep->pool_out; e.ldp = ep->ldp; e.pool_rows = ep->pool_rows;
         e.Cs = reinterpret_cast<unsigned char*>(ep->split_out); e.ldcs = ep->ld_split; e.cs_scale = ep->split_scale;
         if (e.act < 0 || e.act > 3) return UA_EINVAL;
         if (e.rga && e.group_rows <= 0) return UA_EINVAL;
-        if (e.pool && (ep->pool_rows != 64 || M % 64 != 0)) return UA_EUNSUPPORTED;
+        if (e.pool && ((ep->pool_rows != 64 && ep->pool_rows != 32) || M % ep->pool_rows != 0)) return UA_EUNSUPPORTED;
         if (e.act == 3 && (N % 64 != 0 || e.rga || e.scale || e.shift)) return UA_EUNSUPPORTED;
     }
     if (!C && !e.pool && !e.Cs) return UA_EINVAL;

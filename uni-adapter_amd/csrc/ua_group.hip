@@ -154,9 +154,9 @@ knn_group_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb, c
         if (sel) {
             const int pos = base + __popcll(sm & lt_mask);
             float* o = feat + (grp + pos) * (size_t)ldf;
-            const float* q = rgb + ((size_t)b * N + i) * 3;
             o[0] = s_xyz[3 * i] - cx; o[1] = s_xyz[3 * i + 1] - cy; o[2] = s_xyz[3 * i + 2] - cz;   // :124
-            o[3] = q[0]; o[4] = q[1]; o[5] = q[2];                                                  // :126
+            if (rgb) { const float* q = rgb + ((size_t)b * N + i) * 3; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; }   // :126
+            else { o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; }          // xyz-only variant (models/ulip/pointbert/dvae.py:152-181)
             for (int t = 6; t < ldf; ++t) o[t] = 0.f;
             if (idx_out) idx_out[grp + pos] = i;
         }
@@ -183,7 +183,7 @@ extern "C" int ua_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int32_t
 extern "C" int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
                             int32_t B, int32_t N, int32_t G, int32_t S,
                             float* feat, int32_t ldf, int32_t* idx, void* stream) {
-    UA_CHECK_PTR(xyz); UA_CHECK_PTR(rgb); UA_CHECK_PTR(centers); UA_CHECK_PTR(feat);
+    UA_CHECK_PTR(xyz); UA_CHECK_PTR(centers); UA_CHECK_PTR(feat);       // rgb may be NULL (xyz-only groups)
     if (B <= 0 || N <= 0 || G <= 0 || S <= 0 || S > N || ldf < 6) return UA_EINVAL;
     if (N > 4096 || S > 256) return UA_EUNSUPPORTED;
     const size_t lds = (size_t)N * 4 * sizeof(float);

@@ -91,7 +91,54 @@ assemble_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ 
     reinterpret_cast<float4*>(x)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);   // :208
 }
 
+// x[b*G+g] += pos[b*G+g] ; x[Bc*G+b] += cls_pos   (PointBERT re-adds the positional embedding before
+// every block: models/ulip/pointbert/point_encoder.py:95-98)
+__global__ void __launch_bounds__(256)
+add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, const float* __restrict__ cls_pos,
+               int n_patch_rows, int n_rows, int C4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n_rows * C4) return;
+    const size_t row = i / C4, c = i % C4;
+    const float4 p = (row < (size_t)n_patch_rows) ? reinterpret_cast<const float4*>(pos)[i] : reinterpret_cast<const float4*>(cls_pos)[c];
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+
+// out[b, 0:C] = x[Bc*G+b] (CLS) ; out[b, C:2C] = max_g x[b*G+g]   (point_encoder.py:190: cat[cls, max])
+__global__ void __launch_bounds__(256)
+cls_max_concat_kernel(const float* __restrict__ x, float* __restrict__ out, int Bc, int G, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float m = -INFINITY;
+    const float* p = x + (size_t)b * G * C + c;
+    for (int g = 0; g < G; ++g) m = fmaxf(m, p[(size_t)g * C]);
+    out[(size_t)b * 2 * C + c] = x[((size_t)Bc * G + b) * C + c];
+    out[(size_t)b * 2 * C + C + c] = m;
+}
+
 }  // namespace
+
+extern "C" int ua_add_pos(float* x, const float* pos, const float* cls_pos, int32_t Bc, int32_t G, int32_t C, void* stream) {
+    UA_CHECK_PTR(x); UA_CHECK_PTR(pos); UA_CHECK_PTR(cls_pos);
+    UA_CHECK_ALIGN16(x); UA_CHECK_ALIGN16(pos); UA_CHECK_ALIGN16(cls_pos);
+    if (Bc <= 0 || G <= 0 || C <= 0) return UA_EINVAL;
+    if (C % 4) return UA_EUNSUPPORTED;
+    const int rows = Bc * G + Bc;
+    const size_t total = (size_t)rows * (C / 4);
+    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ua::as_stream(stream),
+                       x, pos, cls_pos, Bc * G, rows, C / 4);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_cls_max_concat(const float* x, float* out, int32_t Bc, int32_t G, int32_t C, void* stream) {
+    UA_CHECK_PTR(x); UA_CHECK_PTR(out);
+    if (Bc <= 0 || G <= 0 || C <= 0) return UA_EINVAL;
+    hipLaunchKernelGGL(cls_max_concat_kernel, dim3((C + 255) / 256, Bc), dim3(256), 0, ua::as_stream(stream), x, out, Bc, G, C);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
 
 extern "C" int ua_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
                             float* y, int64_t ldy, int32_t rows, int32_t cols, int32_t cols_pad, void* stream) {

@@ -121,7 +121,8 @@ class PointcloudEncoder(nn.Module):
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_group: int, group_size: int, num_heads: int,
                  device=None, prefix: str = 'point_encoder.', ln_eps: float = 1e-6, bn_eps: float = 1e-5,
-                 fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8, precision: str = 'f32'):
+                 fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8, precision: str = 'f32',
+                 variant: str = 'uni3d', projection: Optional[torch.Tensor] = None):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('uni_adapter_amd.PointcloudEncoder needs a HIP device (MI355X); no CPU path')
@@ -133,9 +134,21 @@ class PointcloudEncoder(nn.Module):
             raise ValueError("precision must be 'f32' (exact-f32 MFMA) or 'split' (3xf16-split MFMA, fp32-accurate)")
         self.precision = precision
         sp = precision == 'split'
-        if self.group_size != 64:
-            raise NotImplementedError('patch-embed max-pool epilogue is built for group_size 64 (Uni3D)')
+        if self.group_size not in (32, 64):
+            raise NotImplementedError('patch-embed max-pool epilogue is built for group sizes 64 (Uni3D) and 32 (PointBERT)')
+        if variant not in ('uni3d', 'ulip'):
+            raise ValueError("variant must be 'uni3d' or 'ulip'")
+        self.variant = variant
         sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        if variant == 'ulip':
+            # PointBERT layout (models/ulip/pointbert/point_encoder.py:101-135) -> the internal key names
+            ren = {}
+            for k, v in sd.items():
+                k2 = k.replace('reduce_dim.', 'encoder2trans.').replace('blocks.blocks.', 'visual.blocks.')
+                if k2 in ('norm.weight', 'norm.bias'):
+                    k2 = 'ulip_' + k2
+                ren[k2] = v
+            sd = ren
         d = lambda t: t.detach().to(self.dev, torch.float32).contiguous()
 
         def bn_affine(name):                       # eval BatchNorm1d -> per-channel scale/shift
@@ -164,8 +177,16 @@ class PointcloudEncoder(nn.Module):
         # ---- bridges / positional MLP (:175-186) ----
         self.w_e2t = d(sd['encoder2trans.weight']); self.b_e2t = d(sd['encoder2trans.bias'])
         self.trans_dim = self.w_e2t.shape[0]
-        self.w_t2e = d(sd['trans2embed.weight']); self.b_t2e = d(sd['trans2embed.bias'])
-        self.embed_dim = self.w_t2e.shape[0]
+        if variant == 'uni3d':
+            self.w_t2e = d(sd['trans2embed.weight']); self.b_t2e = d(sd['trans2embed.bias'])
+            self.embed_dim = self.w_t2e.shape[0]
+        else:
+            # ULIP: pc_embed = cat[cls, max(tokens)] @ pc_projection (models/ulip/ulip_model.py:15-18)
+            if projection is None:
+                raise ValueError("variant 'ulip' needs the pc_projection matrix (2*trans_dim, embed)")
+            self.w_t2e = d(projection.t()); self.b_t2e = None
+            self.embed_dim = self.w_t2e.shape[0]
+            self.ulip_norm = (d(sd['ulip_norm.weight']), d(sd['ulip_norm.bias']))
         self.w_p0 = d(torch.nn.functional.pad(sd['pos_embed.0.weight'], (0, 1))); self.b_p0 = d(sd['pos_embed.0.bias'])
         self.w_p2 = d(sd['pos_embed.2.weight']); self.b_p2 = d(sd['pos_embed.2.bias'])
         self.cls_token = d(sd['cls_token'].reshape(-1)); self.cls_pos = d(sd['cls_pos'].reshape(-1))
@@ -247,12 +268,16 @@ class PointcloudEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, pts, colors, return_tokens=False):
-        """pts, colors: (Bc,N,3) fp32 on device -> (Bc, embed_dim)  (models/point_encoder.py:192-223)."""
+    def forward(self, pts, colors=None, return_tokens=False):
+        """pts, colors: (Bc,N,3) fp32 on device -> (Bc, embed_dim)  (models/point_encoder.py:192-223;
+        variant 'ulip': xyz only, models/ulip/pointbert/point_encoder.py:173-192)."""
         Bc, N, _ = pts.shape
         G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
         pts = pts.to(self.dev, torch.float32).contiguous()
-        colors = colors.to(self.dev, torch.float32).contiguous()
+        if self.variant == 'uni3d':
+            colors = colors.to(self.dev, torch.float32).contiguous()
+        else:
+            colors = None
         w = self._workspace(Bc)
         st = lib.stream_ptr()
         # ---- grouping (:108-127) ----
@@ -264,30 +289,30 @@ class PointcloudEncoder(nn.Module):
         for c0 in range(0, Bc, pc):
             nb = min(pc, Bc - c0)
             Mp, Mg = nb * G * S, nb * G
-            lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr(), w['centers'][c0:].data_ptr(),
+            lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr() if colors is not None else None, w['centers'][c0:].data_ptr(),
                      nb, N, G, S, w['feat'].data_ptr(), 8, None, st)
             n3 = self.n3
             if not sp:
                 _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
                       alg_flops=2.0 * Mp * 128 * self.in_ch)
                 _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
-                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=64)
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S)
                 _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
                 _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
                       group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
                 _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
-                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
             else:
                 # same chain; the per-point activations h1 / loc / h3 only ever exist in split form
                 _gemm(w['feat'], 8, self.w1, None, 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
                       alg_flops=2.0 * Mp * 128 * self.in_ch, split_out=w['h1'], ld_split=128)
                 _gemm(w['h1'], 128, self.w2, None, self.c_loc, Mp, self.c_loc, 128, bias=self.b2, a_scale=1.0,
-                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=64, split_out=w['loc'], ld_split=self.c_loc)
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S, split_out=w['loc'], ld_split=self.c_loc)
                 _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
                 _gemm(w['loc'], self.c_loc, self.w3l, None, n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
                       group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU, a_scale=1.0, split_out=w['h3'], ld_split=n3)
                 _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4, a_scale=1.0,
-                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=64)
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
         # ---- token assembly (:198-208) ----
         Mg = Bc * G
         _gemm(w['tok'], self.enc_dim, self.w_e2t, w['tokc'], Cd, Mg, Cd, self.enc_dim, bias=self.b_e2t)
@@ -298,7 +323,11 @@ class PointcloudEncoder(nn.Module):
         # ---- transformer blocks (:217-218) ----
         rows = Mg + Bc
         x = w['x']
+        first = True
         for b in self.blocks:
+            if self.variant == 'ulip' and not first:      # x = block(x + pos) in every block (pointbert/point_encoder.py:95-98)
+                lib.call('ua_add_pos', x.data_ptr(), w['pos'].data_ptr(), self.cls_pos.data_ptr(), Bc, G, Cd, st)
+            first = False
             # split mode: every GEMM operand is an H32L32 pair written directly by its producer (LN
             # kernel) or converted once (attention output); x, qkv and the SwiGLU hidden stay fp32.
             s1 = b.ln1_scale if sp else None
@@ -342,15 +371,22 @@ class PointcloudEncoder(nn.Module):
                 lib.call('ua_split_f16', hid.data_ptr(), ld_h, w['hidn'].data_ptr(), ld_h, rows, b.H, Hp, 1.0, st)
                 hid, s_h = w['hidn'], 1.0
             _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H, a_scale=s_h)
-        # ---- head (:219-222) on the CLS rows ----
-        cls = x[Mg:]
-        cur, nxt = cls, w['cls']
-        for nrm in (self.norm, self.fc_norm):
-            if nrm is not None:
-                _ln(cur, Cd, nrm[0], nrm[1], self.ln_eps, nxt, Cd, Bc, Cd, Cd)
-                cur, nxt = nxt, (w['cls2'] if nxt is w['cls'] else w['cls'])
         out = torch.empty(Bc, self.embed_dim, device=self.dev, dtype=torch.float32)
-        _gemm(cur, Cd, self.w_t2e, out, self.embed_dim, Bc, self.embed_dim, Cd, bias=self.b_t2e)
+        if self.variant == 'uni3d':
+            # ---- head (:219-222) on the CLS rows ----
+            cls = x[Mg:]
+            cur, nxt = cls, w['cls']
+            for nrm in (self.norm, self.fc_norm):
+                if nrm is not None:
+                    _ln(cur, Cd, nrm[0], nrm[1], self.ln_eps, nxt, Cd, Bc, Cd, Cd)
+                    cur, nxt = nxt, (w['cls2'] if nxt is w['cls'] else w['cls'])
+            _gemm(cur, Cd, self.w_t2e, out, self.embed_dim, Bc, self.embed_dim, Cd, bias=self.b_t2e)
+        else:
+            # ---- PointBERT head: LN on all tokens, cat[cls, max over patch tokens], @ pc_projection ----
+            _ln(x, Cd, self.ulip_norm[0], self.ulip_norm[1], self.ln_eps, w['att'], Cd, rows, Cd, Cd)
+            cat = torch.empty(Bc, 2 * Cd, device=self.dev, dtype=torch.float32)
+            lib.call('ua_cls_max_concat', w['att'].data_ptr(), cat.data_ptr(), Bc, G, Cd, st)
+            _gemm(cat, 2 * Cd, self.w_t2e, out, self.embed_dim, Bc, self.embed_dim, 2 * Cd)
         if return_tokens:
             # reference token order: [cls, patch tokens] per cloud
             tokens = torch.cat([x[Mg:].view(Bc, 1, Cd), x[:Mg].view(Bc, G, Cd)], 1)
@@ -366,7 +402,7 @@ class PointcloudEncoder(nn.Module):
         for b in self.blocks:
             f += 2 * T * Cd * Cd * 4 + 4 * T * T * Cd
             f += 2 * T * Cd * b.H * (3 if b.act == ACT_SWIGLU else 2)
-        f += 2 * Cd * self.embed_dim
+        f += 2 * Cd * self.embed_dim * (2 if self.variant == 'ulip' else 1)
         return f
 
 
@@ -398,3 +434,24 @@ def create_uni3d_from_state_dict(state_dict, args=None, num_group=None, group_si
     num_heads = num_heads or trans_dim // 64
     enc = PointcloudEncoder(sd, num_group, group_size, num_heads, **kw)
     return Uni3D(enc, sd.get('logit_scale'))
+
+
+class ULIP(nn.Module):
+    """Mirror of models/ulip/ulip_model.py:6-18: `model(xyz[B,N,3]) -> (B, embed)`."""
+
+    def __init__(self, point_encoder: PointcloudEncoder):
+        super().__init__()
+        self.point_encoder = point_encoder
+
+    def forward(self, pc):
+        return self.point_encoder(pc[:, :, :3].contiguous())
+
+
+def create_ulip_from_state_dict(state_dict, num_group=512, group_size=32, num_heads=6, **kw):
+    """ULIP-2 PointBERT (`models/ulip/pointbert/PointTransformer_8192point.yaml:15-25`) from a
+    checkpoint-layout dict: `point_encoder.*` keys of PointTransformer + `pc_projection`."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+    kw.setdefault('ln_eps', 1e-5)                  # nn.LayerNorm default (point_encoder.py:40,135)
+    kw.setdefault('fps_skip_eps', -1.0)            # pure-torch FPS of models/ulip/pointbert/misc.py:40-60
+    enc = PointcloudEncoder(sd, num_group, group_size, num_heads, variant='ulip', projection=sd['pc_projection'], **kw)
+    return ULIP(enc)

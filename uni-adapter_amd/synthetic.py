@@ -46,6 +46,47 @@ def uni3d_state_dict(seed=0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=
     return sd
 
 
+def ulip_state_dict(seed=0, trans_dim=384, embed_dim=512, enc_dim=256, depth=12, device='cpu', std=0.02):
+    """Random-init weights in the ULIP-2 PointBERT key layout (models/ulip/pointbert/point_encoder.py:121-170,
+    models/ulip/ulip_model.py:11-13)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    C = trans_dim
+    P = 'point_encoder.'
+    sd = {}
+    rn = lambda *s, scale=1.0: torch.randn(*s, generator=g, device=device) * scale
+
+    def lin(name, co, ci, bias=True):
+        sd[P + name + '.weight'] = rn(co, ci, scale=1 / math.sqrt(ci))
+        if bias:
+            sd[P + name + '.bias'] = rn(co, scale=std)
+
+    def ln(name, c):
+        sd[P + name + '.weight'] = 1 + rn(c, scale=0.05); sd[P + name + '.bias'] = rn(c, scale=0.05)
+
+    def conv(name, co, ci):
+        sd[P + name + '.weight'] = rn(co, ci, 1, scale=1 / math.sqrt(ci)); sd[P + name + '.bias'] = rn(co, scale=std)
+
+    def bn(name, c):
+        sd[P + name + '.weight'] = 1 + rn(c, scale=0.1); sd[P + name + '.bias'] = rn(c, scale=0.1)
+        sd[P + name + '.running_mean'] = rn(c, scale=0.1)
+        sd[P + name + '.running_var'] = 1 + 0.2 * torch.rand(c, generator=g, device=device)
+
+    conv('encoder.first_conv.0', 128, 3); bn('encoder.first_conv.1', 128); conv('encoder.first_conv.3', 256, 128)
+    conv('encoder.second_conv.0', 512, 512); bn('encoder.second_conv.1', 512); conv('encoder.second_conv.3', enc_dim, 512)
+    lin('reduce_dim', C, enc_dim)
+    sd[P + 'cls_token'] = rn(1, 1, C, scale=std); sd[P + 'cls_pos'] = rn(1, 1, C, scale=0.1)
+    lin('pos_embed.0', 128, 3); lin('pos_embed.2', C, 128)
+    for i in range(depth):
+        b = f'blocks.blocks.{i}.'
+        ln(b + 'norm1', C); ln(b + 'norm2', C)
+        lin(b + 'attn.qkv', 3 * C, C, bias=False); lin(b + 'attn.proj', C, C)
+        lin(b + 'mlp.fc1', 4 * C, C); lin(b + 'mlp.fc2', C, 4 * C)
+    ln('norm', C)
+    sd['pc_projection'] = rn(2 * C, embed_dim, scale=1 / math.sqrt(2 * C))
+    sd['logit_scale'] = torch.tensor(math.log(1 / 0.07), device=device)
+    return sd
+
+
 def point_clouds(n, n_points=1024, seed=42, device='cpu'):
     """randn clouds scaled into the unit sphere, rgb = ones (data/tta_datasets.py:127)."""
     g = torch.Generator(device=device).manual_seed(seed)
