@@ -154,7 +154,7 @@ int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
                  float* feat, int32_t ldf, int32_t* idx, void* stream);
 
 /* Epilogue of ua_gemm; all pointers optional (NULL = skipped).  Order of operations:
- *   v = acc + bias[n] + rowgroup_add[m / group_rows, n]
+ *   v = acc + (bias[n] + rowgroup_add[m / group_rows, n])     (group_rows: a multiple of 32)
  *   v = v*scale[n] + shift[n]                (eval BatchNorm, models/point_encoder.py:135,141)
  *   act: 0 none | 1 ReLU | 2 GELU(erf) | 3 SwiGLU (columns come in blocks of 32 gate / 32 up:
  *        out[:, j] = silu(gate)*up, N_out = N/2; timm SwiGLU of EvaBlock)

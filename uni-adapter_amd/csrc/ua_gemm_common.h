@@ -61,8 +61,12 @@ __device__ __forceinline__ void stage_64x64(float* stage, const f32x16& a00, con
 // float4 epilogue of one staged 64x64 sub-tile owned by one wave.  mbase: first output row;
 // ncol_base: first INPUT column of the sub-tile (multiple of 64).  Every lane handles 4 consecutive
 // columns (c4) of rows lr, lr+4, ...; C is written in 256-byte row segments with 16-byte stores.
-__device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
-    const bool swiglu = g.act == 3;
+// FULL: the sub-tile lies entirely inside the matrix - no per-lane row / column guards.  ACT is a
+// template parameter so the activation switch is outside the row loop; the optional operands are
+// wave-uniform (scalar) branches and all row addresses advance by pointer increments.
+template <bool FULL, int ACT>
+__device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+    constexpr bool swiglu = ACT == 3;
     const int lr = lane >> 4, c4 = (lane & 15) * 4;
     const int ncol0 = ncol_base + c4;                                // input column of .x
     const int nout0 = swiglu ? ncol_base / 2 + c4 : ncol0;           // output column of .x
@@ -71,54 +75,76 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
     auto ld4 = [&](const float* p, int n, int lim, float fill) {     // guarded float4 of a per-column vector
         float4 r = make_float4(fill, fill, fill, fill);
         if (p) {
-            if (n + 3 < lim) r = *reinterpret_cast<const float4*>(p + n);
+            if (FULL || n + 3 < lim) r = *reinterpret_cast<const float4*>(p + n);
             else { if (n < lim) r.x = p[n]; if (n + 1 < lim) r.y = p[n + 1]; if (n + 2 < lim) r.z = p[n + 2]; }
         }
         return r;
     };
-    const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
-    const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);
-    const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
+    auto st4 = [&](float* q, const float4& v) {
+        if (FULL || nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = v;
+        else { if (nout0 < n_out) q[0] = v.x; if (nout0 + 1 < n_out) q[1] = v.y; if (nout0 + 2 < n_out) q[2] = v.z; }
+    };
     const float as = g.acc_scale;
+    const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
+    const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);                 // v = (acc*as + bias + rga) * scale + shift
+    const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
+    // Every global LOAD of the sub-tile is issued here, before the first store: vmcnt counts loads and
+    // stores in one in-order counter, so a load inside the store loop would make each iteration wait
+    // for the previous iteration's store to be acknowledged.
+    // row-group addend (group_rows is a multiple of 32): one vector for rows 0..31, one for rows 32..63
+    float4 ba = b4, bb = b4;
+    if (g.rga) {
+        if (FULL || mbase < g.M) {
+            const float4 a = ld4(g.rga + (size_t)(mbase / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
+            ba.x += a.x; ba.y += a.y; ba.z += a.z; ba.w += a.w;
+        }
+        if (FULL || mbase + 32 < g.M) {
+            const float4 a = ld4(g.rga + (size_t)((mbase + 32) / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
+            bb.x += a.x; bb.y += a.y; bb.z += a.z; bb.w += a.w;
+        }
+    }
+    const int m_first = mbase + lr;
+    float4 res[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) res[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.residual && active) {
+        const float* rp = g.residual + (size_t)m_first * g.ldr;            // ld4 adds the column
+        const size_t rstep = (size_t)4 * g.ldr;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (FULL || m_first + p * 4 < g.M) res[p] = ld4(rp + p * rstep, nout0, n_out, 0.f);
+    }
+    const bool affine = g.scale || g.shift;
     float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
     const bool pool32 = g.pool_rows == 32;
-#pragma unroll 4
+    const float* sp = stage + lr * EP_LD + c4;
+    float* cp = g.C ? g.C + (size_t)m_first * g.ldc + nout0 : nullptr;
+    unsigned char* qp = g.Cs ? g.Cs + (size_t)m_first * g.ldcs * 4 + split_col_off(nout0) : nullptr;
+    const size_t cstep = (size_t)4 * g.ldc, qstep = (size_t)16 * g.ldcs;
+#pragma unroll
     for (int p = 0; p < 16; ++p) {
-        const int r = p * 4 + lr, m = mbase + r;
-        float4 v = *reinterpret_cast<const float4*>(stage + r * EP_LD + c4);
-        v.x = v.x * as + b4.x; v.y = v.y * as + b4.y; v.z = v.z * as + b4.z; v.w = v.w * as + b4.w;
-        const bool row_ok = m < g.M;
-        if (g.rga && row_ok) {
-            const float4 a = ld4(g.rga + (size_t)(m / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-        if (g.scale) { v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
-        if (g.shift) { v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w; }
-        if (g.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        else if (g.act == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        float4 v = *reinterpret_cast<const float4*>(sp + p * 4 * EP_LD);
+        const float4 bp = p < 8 ? ba : bb;
+        v.x = v.x * as + bp.x; v.y = v.y * as + bp.y; v.z = v.z * as + bp.z; v.w = v.w * as + bp.w;
+        const bool row_ok = FULL || m_first + p * 4 < g.M;
+        if (affine) { v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w; }
+        if (ACT == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (ACT == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         else if (swiglu) {
             // the up-projection of column c sits 32 columns to the right = 8 lanes up in this row
             float4 u;
             u.x = __shfl_down(v.x, 8); u.y = __shfl_down(v.y, 8); u.z = __shfl_down(v.z, 8); u.w = __shfl_down(v.w, 8);
             v.x = silu(v.x) * u.x; v.y = silu(v.y) * u.y; v.z = silu(v.z) * u.z; v.w = silu(v.w) * u.w;
         }
+        v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
         if (row_ok && active) {
-            if (g.residual) {
-                const float4 a = ld4(g.residual + (size_t)m * g.ldr, nout0, n_out, 0.f);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-            }
-            if (g.C) {
-                float* c = g.C + (size_t)m * g.ldc + nout0;
-                if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(c) = v;
-                else { if (nout0 < n_out) c[0] = v.x; if (nout0 + 1 < n_out) c[1] = v.y; if (nout0 + 2 < n_out) c[2] = v.z; }
-            }
-            if (g.Cs && nout0 + 3 < n_out) {                          // n_out % 4 == 0 is required with Cs
+            if (cp) st4(cp + p * cstep, v);
+            if (qp && (FULL || nout0 + 3 < n_out)) {                  // n_out % 4 == 0 is required with Cs
                 f16x4 hi, lo;
                 split4(v, g.cs_scale, hi, lo);
-                unsigned char* q = g.Cs + (size_t)m * g.ldcs * 4 + split_col_off(nout0);
-                *reinterpret_cast<f16x4*>(q) = hi;
-                *reinterpret_cast<f16x4*>(q + 64) = lo;
+                *reinterpret_cast<f16x4*>(qp + p * qstep) = hi;
+                *reinterpret_cast<f16x4*>(qp + p * qstep + 64) = lo;
             }
             if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
             else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
@@ -137,18 +163,29 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
                 pm2.z = fmaxf(pm2.z, __shfl_xor(pm2.z, o)); pm2.w = fmaxf(pm2.w, __shfl_xor(pm2.w, o));
             }
         }
-        auto put = [&](float* q, const float4& v) {
-            if (nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = v;
-            else { if (nout0 < n_out) q[0] = v.x; if (nout0 + 1 < n_out) q[1] = v.y; if (nout0 + 2 < n_out) q[2] = v.z; }
-        };
-        if (lr == 0 && mbase < g.M) {
-            if (!pool32) put(g.pool + (size_t)(mbase / 64) * g.ldp + nout0, pm);
+        if (lr == 0 && active && (FULL || mbase < g.M)) {
+            if (!pool32) st4(g.pool + (size_t)(mbase / 64) * g.ldp + nout0, pm);
             else {
-                put(g.pool + (size_t)(mbase / 32) * g.ldp + nout0, pm);
-                if (mbase + 32 < g.M) put(g.pool + (size_t)(mbase / 32 + 1) * g.ldp + nout0, pm2);
+                st4(g.pool + (size_t)(mbase / 32) * g.ldp + nout0, pm);
+                if (FULL || mbase + 32 < g.M) st4(g.pool + (size_t)(mbase / 32 + 1) * g.ldp + nout0, pm2);
             }
         }
     }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void epilogue_64x64_act(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+    switch (g.act) {                                                 // wave-uniform
+        case 1:  epilogue_64x64_impl<FULL, 1>(g, stage, lane, mbase, ncol_base); break;
+        case 2:  epilogue_64x64_impl<FULL, 2>(g, stage, lane, mbase, ncol_base); break;
+        case 3:  epilogue_64x64_impl<FULL, 3>(g, stage, lane, mbase, ncol_base); break;
+        default: epilogue_64x64_impl<FULL, 0>(g, stage, lane, mbase, ncol_base); break;
+    }
+}
+
+__device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+    if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base);   // wave-uniform
+    else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base);
 }
 
 // Host-side validation + translation of the public epilogue descriptor (shared by both entry points).
@@ -163,6 +200,7 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
         e.Cs = reinterpret_cast<unsigned char*>(ep->split_out); e.ldcs = ep->ld_split; e.cs_scale = ep->split_scale;
         if (e.act < 0 || e.act > 3) return UA_EINVAL;
         if (e.rga && e.group_rows <= 0) return UA_EINVAL;
+        if (e.rga && e.group_rows % 32 != 0) return UA_EUNSUPPORTED;    // the epilogue holds one addend per 32 rows
         if (e.pool && ((ep->pool_rows != 64 && ep->pool_rows != 32) || M % ep->pool_rows != 0)) return UA_EUNSUPPORTED;
         if (e.act == 3 && (N % 64 != 0 || e.rga || e.scale || e.shift)) return UA_EUNSUPPORTED;
     }

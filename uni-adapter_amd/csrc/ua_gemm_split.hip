@@ -36,7 +36,22 @@ struct SplitArgs {
     EpiArgs ep;
     int tiles_n, n_tiles;
     int stagger;                                     // waves 4-7 run half a slab behind waves 0-3
+#ifdef UA_SPLIT_TRACE
+    unsigned long long* trace;                       // [block][wave][6] cycle accumulators (tools/gemm_trace.py)
+    unsigned long long* timeline;                    // [block][8] s_memrealtime (100 MHz): start, main loop end, block end, full?, 4 epilogue stamps (wave 0)
+#endif
 };
+
+#ifdef UA_SPLIT_TRACE
+#define TR_DECL unsigned long long tr_t = 0, tr_acc[6] = {0, 0, 0, 0, 0, 0}
+#define TR_MARK(slot) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); \
+                           tr_acc[slot] += n_ - tr_t; tr_t = n_; } while (0)
+#define TR_START do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_t = __builtin_readcyclecounter(); } while (0)
+#else
+#define TR_DECL
+#define TR_MARK(slot)
+#define TR_START
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -102,9 +117,11 @@ __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n
                 }
     };
     const int nk = g.K / SBK;
+    TR_DECL;
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TR_START;
     // Between two barriers every wave does 2 fragment reads + 2 x 24 MFMAs.  !LATE (waves 0-3):
     // [R(t,0) M(t,0) R(t,1) M(t,1)].  LATE (waves 4-7, the second wave of every SIMD) runs half a slab
     // behind: [M(t-1,1) R(t,0) M(t,0) R(t,1)] - its operands for the first MFMA block are already in
@@ -114,22 +131,183 @@ __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         if (t + 1 < nk) issue(buf ^ 1, (t + 1) * SBK);          // in flight behind this slab's MFMAs
+        TR_MARK(0);                                            // DMA issue
         if (!LATE) {
-            read_frags(buf, 0); mfma_block();
-            read_frags(buf, 1); mfma_block();
+            read_frags(buf, 0); TR_MARK(1); mfma_block(); TR_MARK(2);
+            read_frags(buf, 1); TR_MARK(1); mfma_block(); TR_MARK(2);
         } else {
             if (t > 0) mfma_block();                           // M(t-1, 1), operands read before the barrier
-            read_frags(buf, 0); mfma_block();
-            read_frags(buf, 1);
+            TR_MARK(2);
+            read_frags(buf, 0); TR_MARK(1); mfma_block(); TR_MARK(2);
+            read_frags(buf, 1); TR_MARK(1);
         }
         // the DMA of slab t+1 must have landed (this wave's part) before anyone reads it, and every
         // wave must be done reading slab t before slab t+2 overwrites its buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TR_MARK(3);                                            // DMA wait
         __syncthreads();
+        TR_MARK(4);                                            // barrier wait
     }
+#ifdef UA_SPLIT_TRACE
+    if (g.trace && (tid & 63) == 0) {
+        unsigned long long* o = g.trace + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 6;
+        for (int i = 0; i < 5; ++i) o[i] = tr_acc[i];
+        o[5] = LATE;
+    }
+#endif
     if (LATE) mfma_block();                                    // M(nk-1, 1)
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 8-phase main loop (default).  Per 32-column K-tile each wave runs four phases, one 64x32
+// quadrant (a, b) of its 128x64 output block each, in the order (0,0) (0,1) (1,1) (1,0):
+//
+//     phase p:   ds_read the fragments that change | 2 LDS-DMA pieces of ONE half-tile | [counted waits]
+//                s_barrier | 12 MFMAs (2 row blocks x 2 k16-steps x 3 split products) | s_barrier
+//
+// The LDS holds two K-tile buffers of four half-tiles (A0 A1 B0 B1, 128 rows x 128 B = 16 KiB each;
+// half a of A = the rows a*64..a*64+63 of BOTH wave rows, half b of B = the columns b*32..b*32+31 of
+// all four wave columns), so a quadrant needs exactly one A half and one B half and a half-tile is
+// dead - and can be restaged with the K-tile two ahead - as soon as its quadrant's fragments are
+// in registers:   K-tile t, phase 0: reads B0,A0   stages A1(t+1)
+//                           phase 1: reads B1      stages B0(t+2)
+//                           phase 2: reads A1      stages A0(t+2)
+//                           phase 3: -             stages B1(t+2), s_waitcnt vmcnt(6)
+// vmcnt(6) leaves the three youngest half-tiles (6 pieces per wave) in flight and retires A1(t+1)
+// and everything older, i.e. the whole of K-tile t+1, one phase (two barriers) before its first
+// read.  A half-tile is restaged at least two phases after its last read; B0, restaged one phase
+// after, has its reads retired by lgkmcnt(8) before phase 0's first barrier.  Waves 4-7 run one
+// barrier behind waves 0-3 (one extra s_barrier up front, matched at the end by waves 0-3), so on
+// every SIMD one wave is in its MFMA section while its partner reads LDS and issues DMA: the
+// matrix pipe never waits for a barrier, an LDS burst or a DMA issue of its own wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int S_HALF = 128 * S_ROW;                  // 16,384 B half-tile
+constexpr int S_BUF = 4 * S_HALF;                    // 65,536 B per K-tile buffer: A0 | A1 | B0 | B1
+
+template <bool FULL>
+__device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn, int li, int lh,
+                                                const bool (&on)[4][2], f32x16 (&acc)[4][2]) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
+    const int lane = tid & 63;
+    const int r8 = tid >> 3;                                       // LDS row of this lane's chunk inside a 64-row piece
+    const int cs = (tid & 7) ^ ((r8 >> 1) & 7);                    // source chunk (swizzle on the source side)
+    // source = buffer resource of the tile's row panel (SGPRs) + 32-bit lane offset + scalar K offset:
+    // buffer_load_dwordx4 ... offen lds.  num_records bounds the panel, so a bad offset reads zeros.
+    auto panel = [](const unsigned char* base, long long rows_left, long long ld, int K) {
+        const long long ext = (rows_left - 1) * ld * 4 + (long long)K * 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(ext > 0x7fffffffLL ? 0x7fffffffLL : ext), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t abase = panel(g.A + (size_t)m0 * g.lda * 4, min(g.M - m0, SBM), g.lda, g.K);
+    const __amdgpu_buffer_rsrc_t wbase_g = panel(g.W + (size_t)n0 * g.ldw * 4, min(g.N - n0, SBN), g.ldw, g.K);
+    unsigned pa[2][2];                                             // [half a][piece i = wave row]
+    unsigned pw[2][2];                                             // [half b][piece i]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 128 + h * 64 + r8;                                        // LDS row i*64+r8 of A half h
+            const int col = ((r8 >> 5) + 2 * i) * 64 + h * 32 + (r8 & 31);                // LDS row i*64+r8 of B half h
+            pa[h][i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 4) + cs * 16;
+            pw[h][i] = (unsigned)min(col, g.N - 1 - n0) * (unsigned)(g.ldw * 4) + cs * 16;
+        }
+    const int wbase = __builtin_amdgcn_readfirstlane((tid - lane) * 16);                 // wave-uniform LDS offset of piece 0
+    auto stage = [&](int off, __amdgpu_buffer_rsrc_t base, const unsigned (&src)[2], int kt) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(base, (lds_ptr_t)(slds + off + wbase), 16, src[0], kt * S_ROW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(base, (lds_ptr_t)(slds + off + wbase + S_HALF / 2), 16, src[1], kt * S_ROW, 0, 0);
+    };
+    const int sw = (li >> 1) & 7;
+    const int ph0 = ((0 + lh) ^ sw) * 16, ph1 = ((2 + lh) ^ sw) * 16, pl0 = ((4 + lh) ^ sw) * 16, pl1 = ((6 + lh) ^ sw) * 16;
+    const int aoff = (wm * 64 + li) * S_ROW, boff = 2 * S_HALF + (wn * 32 + li) * S_ROW;
+    f16x8 ah[2][2], al[2][2];                                      // [row block i2][k16 step]
+    f16x8 wh[2][2], wl[2][2];                                      // [half b][k16 step]
+    auto readA = [&](const unsigned char* buf, int a) {
+        const unsigned char* q = buf + a * S_HALF + aoff;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            ah[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph0);
+            al[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl0);
+            ah[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph1);
+            al[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl1);
+        }
+    };
+    auto readB = [&](const unsigned char* buf, int b) {
+        const unsigned char* q = buf + b * S_HALF + boff;
+        wh[b][0] = *reinterpret_cast<const f16x8*>(q + ph0); wl[b][0] = *reinterpret_cast<const f16x8*>(q + pl0);
+        wh[b][1] = *reinterpret_cast<const f16x8*>(q + ph1); wl[b][1] = *reinterpret_cast<const f16x8*>(q + pl1);
+    };
+#define UA_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0)
+    auto mfma_quadrant = [&](int a, int b) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // the two row blocks alternate so that dependent MFMAs are one instruction apart
+            if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wh[b][s], acc[2 * a][b]);
+            if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wh[b][s], acc[2 * a + 1][b]);
+            if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wl[b][s], acc[2 * a][b]);
+            if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wl[b][s], acc[2 * a + 1][b]);
+            if (FULL || on[2 * a][b])     UA_MFMA(al[0][s], wh[b][s], acc[2 * a][b]);
+            if (FULL || on[2 * a + 1][b]) UA_MFMA(al[1][s], wh[b][s], acc[2 * a + 1][b]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define UA_SB() __builtin_amdgcn_sched_barrier(0)
+#define UA_BAR() do { UA_SB(); __builtin_amdgcn_s_barrier(); UA_SB(); } while (0)
+    const int nk = g.K / SBK;
+    // prologue: K-tile 0 complete, K-tile 1 minus A1 in flight (the steady-state staging order)
+    stage(2 * S_HALF, wbase_g, pw[0], 0); stage(0, abase, pa[0], 0); stage(3 * S_HALF, wbase_g, pw[1], 0); stage(S_HALF, abase, pa[1], 0);
+    if (nk > 1) {
+        stage(S_BUF + 2 * S_HALF, wbase_g, pw[0], 1); stage(S_BUF, abase, pa[0], 1); stage(S_BUF + 3 * S_HALF, wbase_g, pw[1], 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    UA_BAR();
+    if (wm == 1) UA_BAR();                                         // waves 4-7 trail by one barrier
+    for (int t = 0; t < nk; ++t) {
+        const int d = t & 1;
+        const unsigned char* buf = slds + d * S_BUF;
+        const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+        // ---- phase 0: quadrant (0,0)
+        readB(buf, 0); UA_SB(); readA(buf, 0); UA_SB();
+        if (s1) stage((d ^ 1) * S_BUF + S_HALF, abase, pa[1], t + 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");         // B0 reads done: it is restaged next phase
+        UA_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 0);
+        UA_BAR();
+        // ---- phase 1: quadrant (0,1)
+        readB(buf, 1); UA_SB();
+        if (s2) stage(d * S_BUF + 2 * S_HALF, wbase_g, pw[0], t + 2);
+        UA_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(0, 1);
+        UA_BAR();
+        // ---- phase 2: quadrant (1,1)
+        readA(buf, 1); UA_SB();
+        if (s2) stage(d * S_BUF, abase, pa[0], t + 2);
+        UA_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_quadrant(1, 1);
+        UA_BAR();
+        // ---- phase 3: quadrant (1,0)
+        if (s2) {
+            stage(d * S_BUF + 3 * S_HALF, wbase_g, pw[1], t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // K-tile t+1 has landed (this wave's pieces)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        UA_BAR();
+        mfma_quadrant(1, 0);
+        UA_BAR();
+    }
+    if (wm == 0) UA_BAR();                                         // re-join the two wave groups
+#undef UA_SB
+#undef UA_BAR
+#undef UA_MFMA
+}
+
+template <int SCHED>
 __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by blockIdx.  The tiles of a
     // partial last row panel (here the 32 CLS rows: almost no MFMA work but a full K walk) take the
@@ -137,6 +315,9 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     // full tiles follow, chunked so that every XCD (blockIdx % 8) owns a contiguous band of row
     // panels (A-panel reuse in its L2) and all XCDs get the same number of full tiles (+-1).
     const int bid = blockIdx.x;
+#ifdef UA_SPLIT_TRACE
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int n_full = (g.M / SBM) * g.tiles_n;
     const int n_thin = g.n_tiles - n_full;
     int tile;
@@ -172,21 +353,55 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             on[i][j] = ((m0 + swm * 128 + i * 32) < g.M) && ((n0 + swn * 64 + j * 32) < g.N);
-    const bool late = g.stagger && __builtin_amdgcn_readfirstlane(wid) >= 4;
-    if (full) { if (late) split_mainloop<true, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
-                else      split_mainloop<true, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
-    else      { if (late) split_mainloop<false, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
-                else      split_mainloop<false, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
+    if constexpr (SCHED == 8) {
+        if (full) split_mainloop8<true>(g, m0, n0, tid, swm, swn, li, lh, on, acc);
+        else      split_mainloop8<false>(g, m0, n0, tid, swm, swn, li, lh, on, acc);
+    } else {
+        const bool late = g.stagger && __builtin_amdgcn_readfirstlane(wid) >= 4;
+        if (full) { if (late) split_mainloop<true, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+                    else      split_mainloop<true, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
+        else      { if (late) split_mainloop<false, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
+                    else      split_mainloop<false, false>(g, m0, n0, tid, wm, wn, li, lh, on, acc); }
+    }
 
+#ifdef UA_SPLIT_TRACE
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B = 139,264 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
     float* stage = reinterpret_cast<float*>(slds) + wid * 64 * ua::EP_LD;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (m0 + wm * 128 + h * 64 >= g.M) break;              // wave-uniform
-        ua::stage_64x64(stage, acc[2 * h][0], acc[2 * h][1], acc[2 * h + 1][0], acc[2 * h + 1][1], li, lh);
-        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128 + h * 64, n0 + wn * 64);
+#ifdef UA_SPLIT_TRACE
+    unsigned long long es[4] = {0, 0, 0, 0};
+#define UA_ES(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define UA_ES(i)
+#endif
+    // (two explicit halves: the accumulator blocks must be indexed statically)
+    if (m0 + wm * 128 < g.M) {                                 // wave-uniform
+        ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
+        UA_ES(0);
+        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128, n0 + wn * 64);
+        UA_ES(1);
     }
+    if (m0 + wm * 128 + 64 < g.M) {
+        ua::stage_64x64(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], li, lh);
+        UA_ES(2);
+        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128 + 64, n0 + wn * 64);
+        UA_ES(3);
+    }
+#undef UA_ES
+#ifdef UA_SPLIT_TRACE
+    if (g.timeline) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long rt_st = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long* o = g.timeline + (size_t)bid * 9;
+            o[0] = rt0; o[1] = rt1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = full ? 1 : 0;
+            o[4] = es[0]; o[5] = es[1]; o[6] = es[2]; o[7] = es[3]; o[8] = rt_st;
+        }
+    }
+#endif
 }
 
 // fp32 -> H32L32, one thread per 4 columns
@@ -223,6 +438,14 @@ extern "C" int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, i
     return UA_OK;
 }
 
+static int g_sched = -1;
+#ifdef UA_SPLIT_TRACE
+extern "C" void ua_gemm_split_set_schedule(int v) { g_sched = v; }
+static unsigned long long* g_trace = nullptr;
+static unsigned long long* g_timeline = nullptr;
+extern "C" void ua_gemm_split_set_trace(unsigned long long* p, unsigned long long* tl) { g_trace = p; g_timeline = tl; }
+#endif
+
 extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const void* W, int64_t ldw, float w_scale,
                              float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                              const ua_gemm_epilogue* ep, void* stream) {
@@ -239,15 +462,23 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
     static const int stagger = [] { const char* e = getenv("UA_SPLIT_STAGGER"); return e ? atoi(e) : 1; }();
+    if (g_sched < 0) { const char* e = getenv("UA_SPLIT_SCHEDULE"); g_sched = e ? atoi(e) : 8; }               // 8 | 2 (A/B aid)
+    const int sched = g_sched;
     g.stagger = stagger;
+#ifdef UA_SPLIT_TRACE
+    g.trace = g_trace; g.timeline = g_timeline;
+#endif
     const size_t lds = (size_t)S_LDS;                                 // 139,264 B
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_split_kernel, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
+    if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
+    else            hipLaunchKernelGGL(gemm_split_kernel<2>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     UA_LAUNCH_CHECK();
     return UA_OK;
 }
