@@ -71,7 +71,7 @@ def main():
                                      C.byref(epi), None)
         lib.ua_gemm_split_set_trace(C.c_void_p(0), C.c_void_p(0))
         ref = None
-        for sched in (2, 8, 2, 8):                         # A/B in one process, interleaved
+        for sched in (2, 8, 16, 2, 8, 16):                 # A/B in one process, interleaved
             lib.ua_gemm_split_set_schedule(sched)
             for _ in range(3):
                 assert run() == 0
@@ -85,24 +85,27 @@ def main():
             if ref is None:
                 ref = Cm.clone()
             same = torch.equal(ref, Cm)
-            print(f'{name}: schedule {sched}: {ms*1e3:.0f} us, {6.0*M*N*K/ms/1e9:.0f} TF executed, bit-identical to first run: {same}', flush=True)
-        for sched in (2, 8):
+            err = (ref - Cm).abs().max().item() / ref.abs().max().item()
+            print(f'{name}: schedule {sched}: {ms*1e3:.0f} us, {6.0*M*N*K/ms/1e9:.0f} TF executed, bit-identical to first run: {same} (max rel diff {err:.1e})', flush=True)
+        for sched in (2, 8, 16):
           lib.ua_gemm_split_set_schedule(sched)
-          tl = torch.zeros(nt * 9, dtype=torch.int64, device=dev)
+          tl = torch.zeros(nt * 10, dtype=torch.int64, device=dev)
           lib.ua_gemm_split_set_trace(C.c_void_p(0), C.c_void_p(tl.data_ptr()))
           run(); torch.cuda.synchronize()
-          T = tl.cpu().reshape(nt, 9).double()
+          T = tl.cpu().reshape(nt, 10).double()
           fullm = T[:, 3] == 1
           ml, ep = (T[:, 1] - T[:, 0]) / 100, (T[:, 2] - T[:, 1]) / 100
-          print(f'    schedule {sched}: full tiles main loop {ml[fullm].mean():.1f} us, epilogue {ep[fullm].mean():.1f} us', flush=True)
+          clk = (T[fullm, 9] / (T[fullm, 1] - T[fullm, 0])).median().item() * 0.1       # cycles per 10 ns -> GHz
+          print(f'    schedule {sched}: full tiles main loop {ml[fullm].mean():.1f} us, epilogue {ep[fullm].mean():.1f} us, in-kernel clock {clk:.2f} GHz, '
+                f'{T[fullm, 9].mean() / (K // 32):.0f} cycles per K-tile', flush=True)
           F = T[fullm]
           seg = [(F[:, 4] - F[:, 1]), (F[:, 5] - F[:, 4]), (F[:, 6] - F[:, 5]), (F[:, 7] - F[:, 6]), (F[:, 8] - F[:, 7]), (F[:, 2] - F[:, 8])]
           print('      wave 0 epilogue (us): stage0 %.2f | rows0 %.2f | stage1 %.2f | rows1 %.2f | store drain %.2f | barrier %.2f' % tuple(float(x.mean()) / 100 for x in seg), flush=True)
         lib.ua_gemm_split_set_schedule(2)
-        tl = torch.zeros(nt * 9, dtype=torch.int64, device=dev)
+        tl = torch.zeros(nt * 10, dtype=torch.int64, device=dev)
         lib.ua_gemm_split_set_trace(C.c_void_p(0), C.c_void_p(tl.data_ptr()))
         run(); torch.cuda.synchronize()
-        T = tl.cpu().reshape(nt, 9).double()
+        T = tl.cpu().reshape(nt, 10).double()
         t0 = T[:, 0].min()
         fullm = T[:, 3] == 1
         st, ml, ep = (T[:, 0] - t0) / 100, (T[:, 1] - T[:, 0]) / 100, (T[:, 2] - T[:, 1]) / 100

@@ -6,6 +6,7 @@
 namespace ua {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -56,6 +57,19 @@ __device__ __forceinline__ void stage_64x64(float* stage, const f32x16& a00, con
         stage[(32 + r) * EP_LD + li] = a10[e];
         stage[(32 + r) * EP_LD + 32 + li] = a11[e];
     }
+}
+
+// Same for 16x16 accumulator blocks (v_mfma_f32_16x16x32_f16): acc[ib0 + ib][jb][j] is row
+// ib*16 + 4*(lane>>4) + j, column jb*16 + (lane&15) of the 64x64 sub-tile (ib, jb = 0..3).
+__device__ __forceinline__ void stage_64x64_b16(float* stage, const f32x4 (&acc)[8][4], int ib0, int lane) {
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                stage[(ib * 16 + 4 * lq + j) * EP_LD + jb * 16 + l15] = acc[ib0 + ib][jb][j];
 }
 
 // float4 epilogue of one staged 64x64 sub-tile owned by one wave.  mbase: first output row;

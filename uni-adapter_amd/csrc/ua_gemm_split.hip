@@ -17,6 +17,7 @@
 // Full row panels are balanced over the XCDs; the thin CLS-row tiles come last (1/8 round).
 #include "ua_gemm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -185,9 +186,13 @@ __device__ __forceinline__ void split_mainloop(const SplitArgs& g, int m0, int n
 constexpr int S_HALF = 128 * S_ROW;                  // 16,384 B half-tile
 constexpr int S_BUF = 4 * S_HALF;                    // 65,536 B per K-tile buffer: A0 | A1 | B0 | B1
 
-template <bool FULL>
-__device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn, int li, int lh,
-                                                const bool (&on)[4][2], f32x16 (&acc)[4][2]) {
+// MF = 32: v_mfma_f32_32x32x16_f16, accumulators f32x16 acc[4][2] (32x32 blocks)
+// MF = 16: v_mfma_f32_16x16x32_f16, accumulators f32x4 acc[8][4] (16x16 blocks; one MFMA covers the whole
+//          32-column K-tile).  Same LDS traffic, registers and matrix-pipe cycles; the chip holds a
+//          higher clock on the 16x16x32 shape under load.
+template <bool FULL, int MF, typename Acc>
+__device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn,
+                                                const bool (&on)[4][2], Acc& acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
     const int lane = tid & 63;
     const int r8 = tid >> 3;                                       // LDS row of this lane's chunk inside a 64-row piece
@@ -216,38 +221,73 @@ __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(base, (lds_ptr_t)(slds + off + wbase), 16, src[0], kt * S_ROW, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(base, (lds_ptr_t)(slds + off + wbase + S_HALF / 2), 16, src[1], kt * S_ROW, 0, 0);
     };
-    const int sw = (li >> 1) & 7;
-    const int ph0 = ((0 + lh) ^ sw) * 16, ph1 = ((2 + lh) ^ sw) * 16, pl0 = ((4 + lh) ^ sw) * 16, pl1 = ((6 + lh) ^ sw) * 16;
-    const int aoff = (wm * 64 + li) * S_ROW, boff = 2 * S_HALF + (wn * 32 + li) * S_ROW;
-    f16x8 ah[2][2], al[2][2];                                      // [row block i2][k16 step]
-    f16x8 wh[2][2], wl[2][2];                                      // [half b][k16 step]
+    // fragment addressing.  MF 32: lane = (row li of a 32-row block, k-half lh), two k16 steps per K-tile
+    // (hi chunk 2s+lh, lo chunk 4+2s+lh).  MF 16: lane = (row lane&15 of a 16-row block, k-group lane>>4),
+    // one k32 step (hi chunk kg, lo chunk 4+kg).  fr[0..3] = chunk byte offsets {hi0, lo0, hi1, lo1} (MF 32)
+    // or {hi, lo, -, -} (MF 16); the row-dependent swizzle is the same function of the LDS row.
+    const int lrow = MF == 32 ? (lane & 31) : (lane & 15);
+    const int lk = MF == 32 ? (lane >> 5) : (lane >> 4);
+    const int sw = (lrow >> 1) & 7;
+    const int ph0 = ((MF == 32 ? 0 + lk : lk) ^ sw) * 16, pl0 = ((4 + lk) ^ sw) * 16;
+    const int ph1 = ((2 + lk) ^ sw) * 16, pl1 = ((6 + lk) ^ sw) * 16;          // MF 32 only
+    const int aoff = (wm * 64 + lrow) * S_ROW, boff = 2 * S_HALF + (wn * 32 + lrow) * S_ROW;
+    f16x8 ah[2][2], al[2][2];                // MF 32: [row block i2][k16 step]; MF 16: [ib2 >> 1][ib2 & 1]
+    f16x8 wh[2][2], wl[2][2];                // MF 32: [half b][k16 step];      MF 16: [half b][col block jb2]
     auto readA = [&](const unsigned char* buf, int a) {
         const unsigned char* q = buf + a * S_HALF + aoff;
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
-            ah[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph0);
-            al[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl0);
-            ah[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph1);
-            al[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl1);
+            if constexpr (MF == 32) {
+                ah[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph0);
+                al[i2][0] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl0);
+                ah[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + ph1);
+                al[i2][1] = *reinterpret_cast<const f16x8*>(q + i2 * 32 * S_ROW + pl1);
+            } else {
+                ah[i2][0] = *reinterpret_cast<const f16x8*>(q + (2 * i2) * 16 * S_ROW + ph0);
+                al[i2][0] = *reinterpret_cast<const f16x8*>(q + (2 * i2) * 16 * S_ROW + pl0);
+                ah[i2][1] = *reinterpret_cast<const f16x8*>(q + (2 * i2 + 1) * 16 * S_ROW + ph0);
+                al[i2][1] = *reinterpret_cast<const f16x8*>(q + (2 * i2 + 1) * 16 * S_ROW + pl0);
+            }
         }
     };
     auto readB = [&](const unsigned char* buf, int b) {
         const unsigned char* q = buf + b * S_HALF + boff;
-        wh[b][0] = *reinterpret_cast<const f16x8*>(q + ph0); wl[b][0] = *reinterpret_cast<const f16x8*>(q + pl0);
-        wh[b][1] = *reinterpret_cast<const f16x8*>(q + ph1); wl[b][1] = *reinterpret_cast<const f16x8*>(q + pl1);
+        if constexpr (MF == 32) {
+            wh[b][0] = *reinterpret_cast<const f16x8*>(q + ph0); wl[b][0] = *reinterpret_cast<const f16x8*>(q + pl0);
+            wh[b][1] = *reinterpret_cast<const f16x8*>(q + ph1); wl[b][1] = *reinterpret_cast<const f16x8*>(q + pl1);
+        } else {
+            wh[b][0] = *reinterpret_cast<const f16x8*>(q + ph0); wl[b][0] = *reinterpret_cast<const f16x8*>(q + pl0);
+            wh[b][1] = *reinterpret_cast<const f16x8*>(q + 16 * S_ROW + ph0); wl[b][1] = *reinterpret_cast<const f16x8*>(q + 16 * S_ROW + pl0);
+        }
     };
 #define UA_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0)
+#define UA_MFMA16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, C_, 0, 0, 0)
     auto mfma_quadrant = [&](int a, int b) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MF == 32) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            // the two row blocks alternate so that dependent MFMAs are one instruction apart
-            if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wh[b][s], acc[2 * a][b]);
-            if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wh[b][s], acc[2 * a + 1][b]);
-            if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wl[b][s], acc[2 * a][b]);
-            if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wl[b][s], acc[2 * a + 1][b]);
-            if (FULL || on[2 * a][b])     UA_MFMA(al[0][s], wh[b][s], acc[2 * a][b]);
-            if (FULL || on[2 * a + 1][b]) UA_MFMA(al[1][s], wh[b][s], acc[2 * a + 1][b]);
+            for (int s = 0; s < 2; ++s) {
+                // the two row blocks alternate so that dependent MFMAs are one instruction apart
+                if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wh[b][s], acc[2 * a][b]);
+                if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wh[b][s], acc[2 * a + 1][b]);
+                if (FULL || on[2 * a][b])     UA_MFMA(ah[0][s], wl[b][s], acc[2 * a][b]);
+                if (FULL || on[2 * a + 1][b]) UA_MFMA(ah[1][s], wl[b][s], acc[2 * a + 1][b]);
+                if (FULL || on[2 * a][b])     UA_MFMA(al[0][s], wh[b][s], acc[2 * a][b]);
+                if (FULL || on[2 * a + 1][b]) UA_MFMA(al[1][s], wh[b][s], acc[2 * a + 1][b]);
+            }
+        } else {
+            // 4 row blocks x 2 column blocks of 16; the three split products of one block are 8 MFMAs apart
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ib2 = 0; ib2 < 4; ++ib2)
+#pragma unroll
+                    for (int jb2 = 0; jb2 < 2; ++jb2)
+                        if (FULL || on[2 * a + (ib2 >> 1)][b]) {
+                            const f16x8& av = term == 2 ? al[ib2 >> 1][ib2 & 1] : ah[ib2 >> 1][ib2 & 1];
+                            const f16x8& bv = term == 1 ? wl[b][jb2] : wh[b][jb2];
+                            UA_MFMA16(av, bv, acc[4 * a + ib2][2 * b + jb2]);
+                        }
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -305,6 +345,7 @@ __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int 
 #undef UA_SB
 #undef UA_BAR
 #undef UA_MFMA
+#undef UA_MFMA16
 }
 
 template <int SCHED>
@@ -317,6 +358,7 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     const int bid = blockIdx.x;
 #ifdef UA_SPLIT_TRACE
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ct0 = __builtin_amdgcn_s_memtime();
 #endif
     const int n_full = (g.M / SBM) * g.tiles_n;
     const int n_thin = g.n_tiles - n_full;
@@ -337,13 +379,23 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     const int wm = wid >> 2, wn = wid & 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    f32x16 acc[4][2];
+    // SCHED 16: 8-phase loop on the 16x16x32 MFMA (acc 8x4 blocks of 16x16); SCHED 8 / 2: 32x32x16 MFMA
+    constexpr bool B16 = SCHED == 16;
+    typedef typename std::conditional<B16, ua::f32x4[8][4], f32x16[4][2]>::type AccT;
+    AccT acc;
+    if constexpr (B16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) acc[i][j] = ua::f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
 
     const bool full = (m0 + SBM <= g.M) && (n0 + SBN <= g.N);
     const int swm = __builtin_amdgcn_readfirstlane(wm), swn = __builtin_amdgcn_readfirstlane(wn);
@@ -353,9 +405,12 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             on[i][j] = ((m0 + swm * 128 + i * 32) < g.M) && ((n0 + swn * 64 + j * 32) < g.N);
-    if constexpr (SCHED == 8) {
-        if (full) split_mainloop8<true>(g, m0, n0, tid, swm, swn, li, lh, on, acc);
-        else      split_mainloop8<false>(g, m0, n0, tid, swm, swn, li, lh, on, acc);
+    if constexpr (SCHED == 16) {
+        if (full) split_mainloop8<true, 16>(g, m0, n0, tid, swm, swn, on, acc);
+        else      split_mainloop8<false, 16>(g, m0, n0, tid, swm, swn, on, acc);
+    } else if constexpr (SCHED == 8) {
+        if (full) split_mainloop8<true, 32>(g, m0, n0, tid, swm, swn, on, acc);
+        else      split_mainloop8<false, 32>(g, m0, n0, tid, swm, swn, on, acc);
     } else {
         const bool late = g.stagger && __builtin_amdgcn_readfirstlane(wid) >= 4;
         if (full) { if (late) split_mainloop<true, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
@@ -366,6 +421,7 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 
 #ifdef UA_SPLIT_TRACE
     const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ct1 = __builtin_amdgcn_s_memtime();
 #endif
     // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B = 139,264 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
@@ -378,13 +434,15 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #endif
     // (two explicit halves: the accumulator blocks must be indexed statically)
     if (m0 + wm * 128 < g.M) {                                 // wave-uniform
-        ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
+        if constexpr (B16) ua::stage_64x64_b16(stage, acc, 0, lane);
+        else ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
         UA_ES(0);
         ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128, n0 + wn * 64);
         UA_ES(1);
     }
     if (m0 + wm * 128 + 64 < g.M) {
-        ua::stage_64x64(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], li, lh);
+        if constexpr (B16) ua::stage_64x64_b16(stage, acc, 4, lane);
+        else ua::stage_64x64(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], li, lh);
         UA_ES(2);
         ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128 + 64, n0 + wn * 64);
         UA_ES(3);
@@ -396,9 +454,9 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
         const unsigned long long rt_st = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
         if (tid == 0) {
-            unsigned long long* o = g.timeline + (size_t)bid * 9;
+            unsigned long long* o = g.timeline + (size_t)bid * 10;
             o[0] = rt0; o[1] = rt1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = full ? 1 : 0;
-            o[4] = es[0]; o[5] = es[1]; o[6] = es[2]; o[7] = es[3]; o[8] = rt_st;
+            o[4] = es[0]; o[5] = es[1]; o[6] = es[2]; o[7] = es[3]; o[8] = rt_st; o[9] = ct1 - ct0;
         }
     }
 #endif
@@ -462,7 +520,7 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
     static const int stagger = [] { const char* e = getenv("UA_SPLIT_STAGGER"); return e ? atoi(e) : 1; }();
-    if (g_sched < 0) { const char* e = getenv("UA_SPLIT_SCHEDULE"); g_sched = e ? atoi(e) : 8; }               // 8 | 2 (A/B aid)
+    if (g_sched < 0) { const char* e = getenv("UA_SPLIT_SCHEDULE"); g_sched = e ? atoi(e) : 16; }              // 16 (default) | 8 | 2: A/B aid
     const int sched = g_sched;
     g.stagger = stagger;
 #ifdef UA_SPLIT_TRACE
@@ -475,9 +533,12 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
         attr_set = true;
     }
-    if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
+    if (sched == 16) hipLaunchKernelGGL(gemm_split_kernel<16>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
+    else if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     else            hipLaunchKernelGGL(gemm_split_kernel<2>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     UA_LAUNCH_CHECK();
     return UA_OK;
