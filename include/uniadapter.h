@@ -133,6 +133,17 @@ int ua_residual_adam(const float* text0, float* res, float* adam_m, float* adam_
                      int32_t K, int32_t D, int32_t step, double lr, double beta1, double beta2,
                      double adam_eps, void* stream);
 
+/* One residual-learning step after ua_align_forward in ONE launch: ua_align_loss + ua_align_backward
+ * + ua_residual_adam with bit-identical results (Uni_Adapter.py:191-270,444-476).  L (K,K), joint
+ * (K,K,M) from ua_align_forward on e; updates res / adam_m / adam_v / e / norm in place; grad_e (K,D)
+ * is workspace and output; loss (1) and grad_ll (K,K,M) are optional outputs; tickets: K int32 that
+ * are zero at the call (left zero on completion).  K <= 128, D % 256 == 0.                       */
+int ua_align_step(const float* mu, const float* inv_var, const float* L, const float* joint,
+                  const float* text0, float* res, float* adam_m, float* adam_v, float* e, float* norm,
+                  int32_t K, int32_t M, int32_t D, int32_t step, double lr, double beta1, double beta2,
+                  double adam_eps, float* loss, float* grad_ll, float* grad_e, int32_t* tickets,
+                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Uni3D point-cloud encoder (models/point_encoder.py, models/uni3d.py, timm EVA02 blocks)
  * ------------------------------------------------------------------------------------------ */
@@ -246,6 +257,7 @@ typedef struct {
     float  *fhat, *faug, *clip_logits, *prob, *dota_scores;          /* scratch: (D),(D),(K),(K),(K)      */
     float  *L, *joint, *grad_ll, *grad_e, *loss;                     /* scratch: (K,K),(K,K,M)x2,(K,D),(1)*/
     float  *inv_var, *row_const;                                     /* scratch: (K,M,D),(K,M)            */
+    int32_t *tickets;                                                /* scratch: (K) int32 (ua_align_step) */
 } ua_tta_state;
 
 /* feats (n,2,D): [:,0] encoder output of the sample, [:,1] of its augmented copy.

@@ -598,3 +598,47 @@ def test_add_pos_and_cls_max_concat(ua):
     ua.call('ua_cls_max_concat', ua.ptr(xd), ua.ptr(out), Bc, G, Cd, ua.stream_ptr())
     ref = torch.cat([want[Bc * G:], want[:Bc * G].reshape(Bc, G, Cd).max(1)[0]], 1)
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize('name,seed', [('g3_alignment_scanobjectnn.npz', 0), ('g3_alignment_scanobjectnn.npz', 1)])
+def test_align_step_fused_is_bit_identical_to_the_three_kernels(ua, golden_dir, name, seed):
+    """ua_align_step (loss + backward + Adam in one launch, cross-workgroup ticket hand-off) against
+    ua_align_loss -> ua_align_backward -> ua_residual_adam on the same inputs, over 3 chained steps."""
+    g = _load(golden_dir, name)
+    K, M = g['pi'].shape; D = g['mu'].shape[2]; eps = float(g['eps'])
+    gen = torch.Generator().manual_seed(seed)
+    mu, var, pi = dev(_t(g['mu'])), dev(_t(g['var'])), dev(_t(g['pi']))
+    text0 = dev(_t(g['text']))
+    iv = torch.empty(K, M, D, device='cuda'); rc = torch.empty(K, M, device='cuda')
+    ua.call('ua_gmm_prepare_alignment', ua.ptr(var), ua.ptr(pi), K, M, D, eps, ua.ptr(iv), ua.ptr(rc), ua.stream_ptr())
+
+    def fresh():
+        res = dev(_t(g['res']) + 1e-3 * seed * torch.randn(K, D, generator=torch.Generator().manual_seed(5)))
+        am = dev(1e-4 * torch.randn(K, D, generator=torch.Generator().manual_seed(6)))
+        av = dev(1e-8 * torch.rand(K, D, generator=torch.Generator().manual_seed(7)))
+        t = text0 + res
+        nrm = t.norm(dim=1).contiguous(); e = (t / nrm[:, None]).contiguous()
+        _KEEP.extend([nrm, e])
+        return res, am, av, e, nrm
+    A, B = fresh(), fresh()
+    L = torch.empty(K, K, device='cuda'); J = torch.empty(K, K, M, device='cuda')
+    gll = torch.empty(K, K, M, device='cuda'); ge = torch.empty(K, D, device='cuda'); loss = torch.empty(1, device='cuda')
+    gll2 = torch.empty(K, K, M, device='cuda'); ge2 = torch.empty(K, D, device='cuda'); loss2 = torch.empty(1, device='cuda')
+    tickets = torch.zeros(K, dtype=torch.int32, device='cuda')
+    for step in (1, 2, 3):
+        res, am, av, e, nrm = A
+        ua.call('ua_align_forward', ua.ptr(mu), ua.ptr(iv), ua.ptr(rc), ua.ptr(e), K, K, M, D, ua.ptr(L), ua.ptr(J), ua.stream_ptr())
+        ua.call('ua_align_loss', ua.ptr(L), ua.ptr(J), K, M, ua.ptr(loss), ua.ptr(gll), ua.stream_ptr())
+        ua.call('ua_align_backward', ua.ptr(mu), ua.ptr(iv), ua.ptr(e), ua.ptr(gll), K, K, M, D, ua.ptr(ge), ua.stream_ptr())
+        ua.call('ua_residual_adam', ua.ptr(text0), ua.ptr(res), ua.ptr(am), ua.ptr(av), ua.ptr(ge), ua.ptr(e), ua.ptr(nrm), K, D, step,
+                1e-3, 0.9, 0.999, 1e-8, ua.stream_ptr())
+        res, am, av, e, nrm = B
+        ua.call('ua_align_forward', ua.ptr(mu), ua.ptr(iv), ua.ptr(rc), ua.ptr(e), K, K, M, D, ua.ptr(L), ua.ptr(J), ua.stream_ptr())
+        ua.call('ua_align_step', ua.ptr(mu), ua.ptr(iv), ua.ptr(L), ua.ptr(J), ua.ptr(text0), ua.ptr(res), ua.ptr(am), ua.ptr(av), ua.ptr(e),
+                ua.ptr(nrm), K, M, D, step, 1e-3, 0.9, 0.999, 1e-8, ua.ptr(loss2), ua.ptr(gll2), ua.ptr(ge2), ua.ptr(tickets, torch.int32),
+                ua.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(loss, loss2) and torch.equal(gll, gll2) and torch.equal(ge, ge2), step
+        for x, y in zip(A, B):
+            assert torch.equal(x, y), step
+        assert int(tickets.abs().sum()) == 0

@@ -135,7 +135,29 @@ def cache():
     print(f'residual step K=40: loglik fwd {t1 * 1e3:.1f} us, align {t2 * 1e3:.1f} us, bwd {t3 * 1e3:.1f} us')
 
 
+def replay():
+    """In-order cache replay alone (ua_tta_chunk, K=40 M=8 D=1024, residual learning on): ms per sample."""
+    import ctypes
+    import numpy as np
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    from uni_adapter_amd import synthetic
+    gpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'g2_stream_modelnet40.npz')
+    text = torch.from_numpy(np.load(gpath)['text']) if os.path.exists(gpath) else synthetic.text_bank(40, 1024)
+    eng = TtaEngine(None, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 8, res_learning=True, chunk=64, device=torch.device('cuda'))
+    n, D, K = 64, 1024, text.shape[0]
+    g = torch.Generator(device='cuda').manual_seed(3)
+    feats = torch.randn(n, 2, D, device='cuda', generator=g) * 0.3 + text.cuda()[torch.randint(0, K, (n,), device='cuda', generator=g)][:, None, :]
+    final = torch.empty(n, K, device='cuda'); preds = torch.empty(n, dtype=torch.int32, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    i0, a0 = 1, 0
+
+    def run():
+        lib.call('ua_tta_chunk', ctypes.byref(eng._state), feats.data_ptr(), None, n, i0, a0, final.data_ptr(), None, preds.data_ptr(), st)
+    med, _ = timeit(run, reps=5, warm=2)
+    print(f'== cache replay: {med / n * 1e3:.1f} us per sample ({n} samples, 10 Adam steps each)')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache']
+    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay']
     for w in which:
         globals()[w]()

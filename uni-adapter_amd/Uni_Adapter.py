@@ -144,6 +144,7 @@ class TtaEngine:
         self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
         self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
         self.inv_var, self.row_const = e(K, M, D), e(K, M)
+        self.tickets = torch.zeros(K, dtype=torch.int32, device=self.dev)      # hand-off counters of ua_align_step
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
         self.count = 0
         self.last_loss = None
@@ -163,6 +164,7 @@ class TtaEngine:
         s.fhat, s.faug, s.clip_logits, s.prob, s.dota_scores = (t.data_ptr() for t in (self.fh, self.fa, self.z, self.prob, self.dz))
         s.L, s.joint, s.grad_ll, s.grad_e, s.loss = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge, self.loss))
         s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
+        s.tickets = self.tickets.data_ptr()
         return s
 
     # -- encoder part: this rank's share of the chunk -------------------------------------

@@ -16,6 +16,7 @@
 // The D-long sums are accumulated in fp64 and rounded to fp32 once, which is at least as
 // accurate as torch's fp32 pairwise sums (|sum| ~ 9e3, fp32 ulp there ~ 1e-3).
 #include "ua_common.h"
+#include <cmath>
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -359,6 +360,286 @@ align_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ inv_var
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One residual-learning step in ONE launch: alignment loss + its gradient (align_loss_kernel of
+// ua_logits.hip), the backward through the log-likelihoods (align_bwd_kernel above) and the Adam
+// update with renormalisation (residual_adam_kernel) - Uni_Adapter.py:191-270,444-476 after the
+// forward.  grid (B = K rows, D/256 column chunks), block 1024.
+//   * every workgroup recomputes the K x K loss statistics from L (K <= 160: <= 25,600 values;
+//     same code and reduction order as align_loss_kernel) and forms ONLY its own row b of the
+//     weights w[b,c,m] - no separate loss launch, no grad_ll round trip;
+//   * its 256 columns of grad_e[b] are accumulated exactly as in align_bwd_kernel;
+//   * the D/256 workgroups of a row hand over through an agent-scope release/acquire ticket;
+//     the last arriver applies the Adam step to row b with its first 256 threads (the block
+//     shape of residual_adam_kernel, so the sums associate identically).
+// Results are bit-identical to the three separate launches.  `tickets` (B int32) must be zero
+// at launch; the last arriver re-zeroes its entry.
+// dynamic LDS: 2*K*K + 3K floats (P, row sums, column sums, diagonal, L).
+// ------------------------------------------------------------------------------------------
+struct AlignStepArgs {
+    const float* mu; const float* inv_var; const float* L; const float* joint;
+    const float* text0; float* res; float* am; float* av; float* e; float* nrm;
+    float* ge; float* loss_out; float* grad_ll; int* tickets;
+    int K, M, D;
+    float step_size, w1, beta2, omb2, bc2_sqrt, adam_eps;
+};
+
+__device__ __forceinline__ float block_max_f(float v, float* scratch) {
+    v = ua::wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float t = scratch[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+// block_sum over the first `nw` waves only (all threads of the block must call it)
+__device__ __forceinline__ double block_sum_first(double v, double* scratch, int nw) {
+    v = ua::wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && w < nw) scratch[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+#ifdef UA_STEP_TRACE
+#define ST_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ST_MARK(i)
+#endif
+constexpr int kStepRows = 12;       // (mu - e) * inv_var rows a wave prefetches into registers (rows wave, wave+16, ...)
+
+__global__ void __launch_bounds__(1024)
+align_step_kernel(AlignStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double s_acc[16][256];
+    __shared__ float s_w[2048];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    __shared__ int s_arg, s_last;
+    const int K = a.K, M = a.M, D = a.D, KM = K * M;
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, nt = 1024;
+    const int wv = tid >> 6, lane = tid & 63;
+    float* P = smem;                 // K*K
+    float* s1 = smem + K * K;        // row sums
+    float* s2 = s1 + K;              // col sums
+    float* dg = s2 + K;              // diagonal
+    float* Ls = dg + K;              // K*K copy of L (read once from L2)
+#ifdef UA_STEP_TRACE
+    unsigned long long st_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ST_MARK(0);
+    // ---- issue the long-latency reads first: the wave's (mu - e) * inv_var rows do not depend on the
+    //      loss, only their weights do.  d[j] is formed with the same operations as align_bwd_kernel.
+    const float4 x = reinterpret_cast<const float4*>(a.e + (size_t)b * D + c * 256)[lane];
+    const bool pre = KM <= 2048;                                // block-uniform (one pass over the weights)
+    // the weight this thread forms after the loss phase needs joint[b, km]; the Adam tail (if this
+    // workgroup turns out to be the row's last arriver) needs the row's state: all requested now.
+    float jpre = 0.f;
+    if (pre && tid < KM) jpre = a.joint[(size_t)b * KM + tid];
+    const size_t orow = (size_t)b * D;
+    float4 p_am = make_float4(0.f, 0.f, 0.f, 0.f), p_av = p_am, p_res = p_am, p_t0 = p_am, p_e = p_am;
+    if (tid < 256 && D == 1024) {
+        p_am = make_float4(a.am[orow + tid], a.am[orow + tid + 256], a.am[orow + tid + 512], a.am[orow + tid + 768]);
+        p_av = make_float4(a.av[orow + tid], a.av[orow + tid + 256], a.av[orow + tid + 512], a.av[orow + tid + 768]);
+        p_res = make_float4(a.res[orow + tid], a.res[orow + tid + 256], a.res[orow + tid + 512], a.res[orow + tid + 768]);
+        p_t0 = make_float4(a.text0[orow + tid], a.text0[orow + tid + 256], a.text0[orow + tid + 512], a.text0[orow + tid + 768]);
+        p_e = make_float4(a.e[orow + tid], a.e[orow + tid + 256], a.e[orow + tid + 512], a.e[orow + tid + 768]);
+    }
+    float4 d[kStepRows];
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < kStepRows; ++j) {
+            const int i = wv + 16 * j;
+            if (i < KM) {
+                const size_t o = (size_t)i * D + c * 256;
+                const float4 m4 = reinterpret_cast<const float4*>(a.mu + o)[lane];
+                const float4 i4 = reinterpret_cast<const float4*>(a.inv_var + o)[lane];
+                d[j] = make_float4((m4.x - x.x) * i4.x, (m4.y - x.y) * i4.y, (m4.z - x.z) * i4.z, (m4.w - x.w) * i4.w);
+            }
+        }
+    }
+    ST_MARK(1);
+    // ---- loss statistics (align_loss_kernel, verbatim arithmetic; L staged in LDS) ----
+    const int n = K * K;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += nt) { const float l = a.L[i]; Ls[i] = l; mx = fmaxf(mx, l); }
+    mx = block_max_f(mx, sf);
+    ST_MARK(2);
+    if (tid == 0) s_arg = n;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) if (Ls[i] == mx) atomicMin(&s_arg, i);
+    for (int i = tid; i < n; i += nt) P[i] = expf(expf(Ls[i] / mx));
+    __syncthreads();
+    ST_MARK(3);
+    for (int r = tid; r < 2 * K; r += nt) {
+        double s = 0.0;
+        if (r < K) { for (int j = 0; j < K; ++j) s += (double)P[r * K + j]; s1[r] = (float)s; }
+        else { const int cidx = r - K; for (int j = 0; j < K; ++j) s += (double)P[j * K + cidx]; s2[cidx] = (float)s; }
+    }
+    for (int i = tid; i < K; i += nt) dg[i] = P[i * K + i];
+    __syncthreads();
+    ST_MARK(4);
+    double part = 0.0;
+    for (int i = tid; i < K; i += nt) part += (double)(dg[i] / s1[i]) + (double)(dg[i] / s2[i]);
+    const double tot = ua::block_sum(part, sd);
+    ST_MARK(5);
+    if (b == 0 && c == 0 && tid == 0 && a.loss_out) *a.loss_out = (float)(-tot / (double)K);
+    const float invK = 1.f / (float)K;
+    double sacc = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        const int r = (int)((unsigned)i / (unsigned)K), cidx = i - r * K;
+        const float eye = (r == cidx) ? 1.f : 0.f;
+        const float dP = -invK * (eye / s1[r] - dg[r] / (s1[r] * s1[r])) - invK * (eye / s2[cidx] - dg[cidx] / (s2[cidx] * s2[cidx]));
+        const float l = Ls[i];
+        const float E = expf(l / mx);
+        const float dLn = dP * P[i] * E;
+        sacc += (double)dLn * (double)l;
+        P[i] = dLn;
+    }
+    const double S = ua::block_sum(sacc, sd);
+    __syncthreads();
+    ST_MARK(6);
+    const int amax = s_arg;
+    const float corr = (float)(-S / ((double)mx * (double)mx));
+    // ---- backward for row b, columns c*256 .. +255 (align_bwd_kernel with w formed in place) ----
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int r0 = 0; r0 < KM; r0 += 2048) {
+        const int nn = min(2048, KM - r0);
+        __syncthreads();
+        for (int i = tid; i < nn; i += nt) {
+            const int km = r0 + i, k = km / M, ik = b * K + k;
+            float G = P[ik] / mx;
+            if (ik == amax) G += corr;
+            const float jv = pre ? jpre : a.joint[(size_t)ik * M + (km - k * M)];       // pre: i == tid == km
+            const float wgt = G * expf(jv - Ls[ik]);
+            s_w[i] = wgt;
+            if (a.grad_ll && c == 0) a.grad_ll[(size_t)b * KM + km] = wgt;
+        }
+        __syncthreads();
+        int i_first = wv;
+        if (pre) {
+#pragma unroll
+            for (int j = 0; j < kStepRows; ++j) {
+                const int i = wv + 16 * j;
+                if (i < nn) {
+                    const float ww = s_w[i];
+                    a0 += (double)(ww * d[j].x); a1 += (double)(ww * d[j].y); a2 += (double)(ww * d[j].z); a3 += (double)(ww * d[j].w);
+                }
+            }
+            i_first = wv + 16 * kStepRows;                     // the rest (same row order) straight from L2
+        }
+        {
+#pragma unroll 4
+            for (int i = i_first; i < nn; i += 16) {
+                const size_t o = (size_t)(r0 + i) * D + c * 256;
+                const float4 m4 = reinterpret_cast<const float4*>(a.mu + o)[lane];
+                const float4 i4 = reinterpret_cast<const float4*>(a.inv_var + o)[lane];
+                const float ww = s_w[i];
+                a0 += (double)(ww * ((m4.x - x.x) * i4.x));
+                a1 += (double)(ww * ((m4.y - x.y) * i4.y));
+                a2 += (double)(ww * ((m4.z - x.z) * i4.z));
+                a3 += (double)(ww * ((m4.w - x.w) * i4.w));
+            }
+        }
+    }
+    s_acc[wv][lane * 4 + 0] = a0; s_acc[wv][lane * 4 + 1] = a1; s_acc[wv][lane * 4 + 2] = a2; s_acc[wv][lane * 4 + 3] = a3;
+    __syncthreads();
+    if (tid < 256) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += s_acc[i][tid];
+        a.ge[(size_t)b * D + c * 256 + tid] = (float)t;
+    }
+    ST_MARK(7);
+    // ---- hand-off: the last of the D/256 workgroups of row b applies Adam to the row ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(&a.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (int)gridDim.y - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.tickets[b] = 0;                                  // the next launch is stream-ordered behind this one
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    ST_MARK(8);
+#ifdef UA_STEP_TRACE
+    if (!s_last) { if (b == 1 && tid == 0 && a.grad_ll) for (int i = 0; i < 9; ++i) a.grad_ll[i] = (float)(st_t[i] - st_t[0]); return; }
+#endif
+    if (!s_last) return;                                   // workgroup-uniform
+    const size_t o = (size_t)b * D;
+    const bool act = tid < 256;                            // residual_adam_kernel's block shape
+    const float nrm = a.nrm[b];
+    if (D == 1024) {
+        // same arithmetic as below with this thread's 4 columns (tid, tid+256, ...) held in registers
+        const float pe[4] = {p_e.x, p_e.y, p_e.z, p_e.w}, pt[4] = {p_t0.x, p_t0.y, p_t0.z, p_t0.w};
+        float pm[4] = {p_am.x, p_am.y, p_am.z, p_am.w}, pv[4] = {p_av.x, p_av.y, p_av.z, p_av.w}, pr[4] = {p_res.x, p_res.y, p_res.z, p_res.w};
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        double dot = 0.0;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gv[q] = a.ge[o + tid + 256 * q]; dot += (double)(gv[q] * pe[q]); }
+        }
+        const float gdote = (float)block_sum_first(dot, sd, 4);
+        double s = 0.0;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = (gv[q] - pe[q] * gdote) / nrm;
+                float m = pm[q], v = pv[q];
+                m = m + a.w1 * (g - m);
+                v = v * a.beta2 + a.omb2 * (g * g);
+                const float den = sqrtf(v) / a.bc2_sqrt + a.adam_eps;
+                const float r = pr[q] + ((-a.step_size) * m) / den;
+                a.am[o + tid + 256 * q] = m; a.av[o + tid + 256 * q] = v; a.res[o + tid + 256 * q] = r;
+                pr[q] = r;
+                const float t = pt[q] + r;
+                s += (double)(t * t);
+            }
+        }
+        const float nn2 = (float)sqrt(block_sum_first(s, sd, 4));
+        if (tid == 0) a.nrm[b] = nn2;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.e[o + tid + 256 * q] = (pt[q] + pr[q]) / nn2;
+        }
+    } else {
+        double dot = 0.0;
+        if (act) for (int i = tid; i < D; i += 256) dot += (double)(a.ge[o + i] * a.e[o + i]);
+        const float gdote = (float)block_sum_first(dot, sd, 4);
+        double s = 0.0;
+        if (act) for (int i = tid; i < D; i += 256) {
+            const float g = (a.ge[o + i] - a.e[o + i] * gdote) / nrm;
+            float m = a.am[o + i], v = a.av[o + i];
+            m = m + a.w1 * (g - m);
+            v = v * a.beta2 + a.omb2 * (g * g);
+            const float den = sqrtf(v) / a.bc2_sqrt + a.adam_eps;
+            const float r = a.res[o + i] + ((-a.step_size) * m) / den;
+            a.am[o + i] = m; a.av[o + i] = v; a.res[o + i] = r;
+            const float t = a.text0[o + i] + r;
+            s += (double)(t * t);
+        }
+        const float nn2 = (float)sqrt(block_sum_first(s, sd, 4));
+        if (tid == 0) a.nrm[b] = nn2;
+        if (act) for (int i = tid; i < D; i += 256) a.e[o + i] = (a.text0[o + i] + a.res[o + i]) / nn2;
+    }
+    ST_MARK(9);
+#ifdef UA_STEP_TRACE
+    if (b == 0 && tid == 0 && a.grad_ll) for (int i = 0; i < 10; ++i) a.grad_ll[16 + i] = (float)(st_t[i] - st_t[0]);
+#endif
+}
+
 template <typename F>
 int dispatch_vec(int D, F&& f) {
     switch (D / 256) {
@@ -489,6 +770,36 @@ extern "C" int ua_align_backward(const float* mu, const float* inv_var, const fl
     if (D % 256 != 0) return UA_EUNSUPPORTED;
     hipLaunchKernelGGL(align_bwd_kernel, dim3(B, D / 256), dim3(1024), 0, ua::as_stream(stream),
                        mu, inv_var, e, grad_ll, K * M, D, grad_e);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_align_step(const float* mu, const float* inv_var, const float* L, const float* joint,
+                             const float* text0, float* res, float* adam_m, float* adam_v, float* e, float* norm,
+                             int32_t K, int32_t M, int32_t D, int32_t step, double lr, double beta1, double beta2,
+                             double adam_eps, float* loss, float* grad_ll, float* grad_e, int32_t* tickets,
+                             void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(inv_var); UA_CHECK_PTR(L); UA_CHECK_PTR(joint); UA_CHECK_PTR(text0);
+    UA_CHECK_PTR(res); UA_CHECK_PTR(adam_m); UA_CHECK_PTR(adam_v); UA_CHECK_PTR(e); UA_CHECK_PTR(norm);
+    UA_CHECK_PTR(grad_e); UA_CHECK_PTR(tickets);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(inv_var); UA_CHECK_ALIGN16(e);
+    if (K <= 0 || M <= 0 || D <= 0 || step <= 0) return UA_EINVAL;
+    if (D % 256 != 0 || K > 128) return UA_EUNSUPPORTED;          // 2 K^2 floats of LDS next to 41 KB static
+    AlignStepArgs a{};
+    a.mu = mu; a.inv_var = inv_var; a.L = L; a.joint = joint; a.text0 = text0; a.res = res; a.am = adam_m; a.av = adam_v;
+    a.e = e; a.nrm = norm; a.ge = grad_e; a.loss_out = loss; a.grad_ll = grad_ll; a.tickets = tickets;
+    a.K = K; a.M = M; a.D = D;
+    // scalar bookkeeping exactly as ua_residual_adam (torch.optim.adam._single_tensor_adam, python floats = double)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.adam_eps = (float)adam_eps;
+    const size_t lds = (size_t)(2 * K * K + 4 * K) * sizeof(float);
+    if (lds > 16 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(align_step_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return UA_ELAUNCH;
+    hipLaunchKernelGGL(align_step_kernel, dim3(K, D / 256), dim3(1024), lds, ua::as_stream(stream), a);
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

@@ -14,6 +14,10 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
     if (targets && !ranks) return UA_EINVAL;
     const float* text = s->res_learning ? s->e : s->text0;                       // Uni_Adapter.py:388-401
     int64_t adam_step = adam_step0;
+    if (s->res_learning) {
+        UA_CHECK_PTR(s->tickets);
+        if (hipMemsetAsync(s->tickets, 0, sizeof(int32_t) * K, ua::as_stream(stream)) != hipSuccess) return UA_ELAUNCH;
+    }
     for (int j = 0; j < n; ++j) {
         const float* f = feats + (size_t)j * 2 * D;
         const float* fa = f + D;
@@ -28,12 +32,17 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
             if ((rc = ua_gmm_prepare_alignment(s->var, s->pi, K, M, D, s->eps, s->inv_var, s->row_const, stream))) return rc;
             for (int it = 0; it < s->res_steps; ++it) {
                 if ((rc = ua_align_forward(s->mu, s->inv_var, s->row_const, s->e, K, K, M, D, s->L, s->joint, stream))) return rc;
-                if ((rc = ua_align_loss(s->L, s->joint, K, M, s->loss, s->grad_ll, stream))) return rc;
-                if ((rc = ua_align_backward(s->mu, s->inv_var, s->e, s->grad_ll, K, K, M, D, s->grad_e, stream))) return rc;
                 ++adam_step;
                 if (adam_step > 0x7fffffff) return UA_EINVAL;
-                if ((rc = ua_residual_adam(s->text0, s->res, s->adam_m, s->adam_v, s->grad_e, s->e, s->norm, K, D,
-                                           (int32_t)adam_step, s->lr, s->beta1, s->beta2, s->adam_eps, stream))) return rc;
+                // loss + gradient, backward and Adam in one launch (bit-identical to the three entry points)
+                if (K > 128) {
+                    if ((rc = ua_align_loss(s->L, s->joint, K, M, s->loss, s->grad_ll, stream))) return rc;
+                    if ((rc = ua_align_backward(s->mu, s->inv_var, s->e, s->grad_ll, K, K, M, D, s->grad_e, stream))) return rc;
+                    if ((rc = ua_residual_adam(s->text0, s->res, s->adam_m, s->adam_v, s->grad_e, s->e, s->norm, K, D,
+                                               (int32_t)adam_step, s->lr, s->beta1, s->beta2, s->adam_eps, stream))) return rc;
+                } else if ((rc = ua_align_step(s->mu, s->inv_var, s->L, s->joint, s->text0, s->res, s->adam_m, s->adam_v, s->e,
+                                        s->norm, K, M, D, (int32_t)adam_step, s->lr, s->beta1, s->beta2, s->adam_eps,
+                                        s->loss, nullptr, s->grad_e, s->tickets, stream))) return rc;
             }
         }
         if ((rc = ua_fuse_logits(s->clip_logits, s->dota_scores, s->c, K, M, s->rho, s->eta, 1,

@@ -42,7 +42,7 @@ class TtaState(C.Structure):
                 ('res', _p), ('adam_m', _p), ('adam_v', _p), ('e', _p), ('norm', _p),
                 ('fhat', _p), ('faug', _p), ('clip_logits', _p), ('prob', _p), ('dota_scores', _p),
                 ('L', _p), ('joint', _p), ('grad_ll', _p), ('grad_e', _p), ('loss', _p),
-                ('inv_var', _p), ('row_const', _p)]
+                ('inv_var', _p), ('row_const', _p), ('tickets', _p)]
 
 
 # name -> argtypes, exactly the declarations of include/uniadapter.h
@@ -59,6 +59,7 @@ SIGNATURES = {
     'ua_align_forward': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     'ua_align_backward': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
     'ua_residual_adam': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _d, _d, _d, _d, _p],
+    'ua_align_step': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _d, _d, _d, _d, _p, _p, _p, _p, _p],
     'ua_fps': [_p, _i32, _i32, _i32, _i32, _f, _p, _p, _p],
     'ua_knn_group': [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p],
     'ua_gemm': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
