@@ -31,7 +31,7 @@ constexpr int VROW = 320;              // LDS bytes per key row of V (256 + 64: 
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
 __global__ void __launch_bounds__(256, 2)
-attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, float c_scale, float v_inv_scale,
+attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, float c2, float v_inv_scale,
                        float* __restrict__ out, long long ldo, unsigned char* __restrict__ out_split, long long ldos,
                        float out_scale, int Bc, int G, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][KT * KROW];
@@ -116,33 +116,40 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
             }
-            const int n_valid = (t < n_pt) ? KT : 1;
+            // ---- online softmax, fp32 (row = lane's query; other half of the row is lane^32).  The raw
+            // scores stay unscaled: with c2 = hd^-0.5 / s^2 * log2(e) > 0 the row maximum is taken on the
+            // raw values and p = 2^(s*c2 - m*c2) is one v_fma + one v_exp_f32 per element.
+            if (t == n_pt) {                                                       // CLS tile: only key 0 exists
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                sacc[e] = (key < n_valid) ? sacc[e] * c_scale : -INFINITY;        // c_scale = hd^-0.5 / s^2 (power of two)
+                for (int e = 0; e < 16; ++e) {
+                    const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (key >= 1) sacc[e] = -INFINITY;
+                }
             }
-            // ---- online softmax, fp32 (row = lane's query; other half of the row is lane^32) ----
             float mt = sacc[0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sacc[e]);
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = expf(m_run - m_new);
+            const float mc = m_new * c2;
             float psum = 0.f;
             f16x8 ph[2], pl[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = expf(sacc[e] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], c2, -mc));
                 psum += p;
                 const _Float16 hi = (_Float16)p;
                 ph[e >> 3][e & 7] = hi;
                 pl[e >> 3][e & 7] = (_Float16)(p - (float)hi);
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {                     // wave-uniform: some row's maximum moved
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);  // exactly 1 for the rows that did not move
+                l_run *= alpha;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                m_run = m_new;
+            }
+            l_run += psum;
             // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; slot i of half lh <-> key (i&3)+8(i>>2)+4lh+16ks ----
             // transposed-read addressing: 16-lane group Gq = lane>>4 handles features 16*(Gq&1).. of the
             // 32-feature block and keys 4*(Gq>>1)+{0..3} (+16ks, +8); lane 4q+p of the group supplies row q,
@@ -221,7 +228,7 @@ extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scal
     if (out_split && (ldos % 32 || ldos < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out_split) & 15) || !(out_scale > 0.f))) return UA_EALIGN;
     if (H > 65535 || Bc > 65535) return UA_EUNSUPPORTED;
     dim3 grid(G / 128 + 1, H, Bc);
-    const float c_scale = 0.125f / (qkv_scale * qkv_scale);           // hd^-0.5 for hd = 64, exact
+    const float c_scale = (0.125f / (qkv_scale * qkv_scale)) * 1.44269504088896340736f;   // hd^-0.5 / s^2 * log2(e)
     hipLaunchKernelGGL(attention_split_kernel, grid, dim3(256), 0, ua::as_stream(stream),
                        reinterpret_cast<const unsigned char*>(qkv), (long long)ldqkv, c_scale, 1.0f / qkv_scale,
                        out, (long long)ldo, reinterpret_cast<unsigned char*>(out_split), (long long)ldos, out_scale, Bc, G, H);
