@@ -45,8 +45,8 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--chunk', type=int, default=31,
                     help='samples per rank per step (31 -> 62 clouds: 256x256 GEMM tile counts land just under multiples of 256 CUs)')
     ap.add_argument('--depth', type=int, default=24)
