@@ -275,6 +275,40 @@ class TtaEngine:
             self.count += n
         return final, ranks, preds
 
+    # -- checkpoint / resume of the adaptation state (absent in the reference) --
+    def state_dict(self):
+        """Everything the stream carries from sample to sample: GMM state, text residuals and their Adam
+        moments, counters.  Plain tensors / ints (loadable with torch.load(weights_only=True))."""
+        self.synchronize()
+        m, r = self.mode_dota_model, self.residuals
+        sd = {'version': 1, 'K': self.K, 'M': self.M, 'D': self.D, 'i': int(self.i), 't': int(m.t), 'count': int(self.count),
+              'correct': self.correct.detach().cpu().clone(),
+              'mu': m.mu.detach().cpu().clone(), 'var': m.var.detach().cpu().clone(), 'pi': m.pi.detach().cpu().clone(),
+              'c': m.c.detach().cpu().clone(), 'class_counts': m.class_counts.detach().cpu().clone()}
+        if r is not None:
+            sd.update(res=r.res.detach().cpu().clone(), adam_m=r.m.detach().cpu().clone(), adam_v=r.v.detach().cpu().clone(),
+                      e=r.e.detach().cpu().clone(), norm=r.norm.detach().cpu().clone(), adam_step=int(r.step))
+        return sd
+
+    def load_state_dict(self, sd):
+        """Resume from `state_dict()`; tensors are copied INTO the existing device buffers (the C-ABI state
+        holds their addresses)."""
+        if (sd['K'], sd['M'], sd['D']) != (self.K, self.M, self.D):
+            raise ValueError(f"state is for K,M,D = {(sd['K'], sd['M'], sd['D'])}, engine has {(self.K, self.M, self.D)}")
+        if ('res' in sd) != (self.residuals is not None):
+            raise ValueError('residual-learning state present in one of checkpoint / engine only')
+        self.synchronize()
+        m, r = self.mode_dota_model, self.residuals
+        for dst, key in ((m.mu, 'mu'), (m.var, 'var'), (m.pi, 'pi'), (m.c, 'c'), (m.class_counts, 'class_counts')):
+            dst.copy_(sd[key].to(dst.device, dst.dtype))
+        m.t = int(sd['t'])
+        if r is not None:
+            for dst, key in ((r.res, 'res'), (r.m, 'adam_m'), (r.v, 'adam_v'), (r.e, 'e'), (r.norm, 'norm')):
+                dst.copy_(sd[key].to(dst.device, dst.dtype))
+            r.step = int(sd['adam_step'])
+        self.i, self.count = int(sd['i']), int(sd['count'])
+        self.correct.copy_(sd['correct'].to(self.correct.device, self.correct.dtype))
+
     def synchronize(self):
         """Wait for all enqueued work of this engine (both streams)."""
         if self.replay_stream is not None:
