@@ -88,6 +88,12 @@ int ua_clip_logits(const float* feat, const float* text, int32_t K, int32_t D, f
                    int32_t n_normalize, float* fhat, float* logits, float* prob, float* entropy,
                    int32_t* pred, void* stream);
 
+/* The sample and its augmented copy in ONE launch (two workgroups): identical to
+ *   ua_clip_logits(feat, text, K, D, scale, 1, fhat, logits, prob, NULL, NULL) and
+ *   ua_clip_logits(feat_aug, text, K, D, scale, 2, faug, NULL, NULL, NULL, NULL)   (Uni_Adapter.py:406,424,429). */
+int ua_clip_logits_pair(const float* feat, const float* feat_aug, const float* text, int32_t K, int32_t D,
+                        float scale, float* fhat, float* faug, float* logits, float* prob, void* stream);
+
 /* Entropy-weighted fusion (Uni_Adapter.py:491-521 incl. the weight-reuse quirk at :512-513):
  *   w = min(rho*mean(c)/batch, eta); d = w*dota; wc=1/(H(clip)+1e-3); wd=1/(H(d)+1e-3);
  *   wc = wc/(wc+wd); wd = wd/(wc+wd); final = wc*clip + wd*d

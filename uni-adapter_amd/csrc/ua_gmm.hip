@@ -16,6 +16,7 @@
 // The D-long sums are accumulated in fp64 and rounded to fp32 once, which is at least as
 // accurate as torch's fp32 pairwise sums (|sum| ~ 9e3, fp32 ulp there ~ 1e-3).
 #include "ua_common.h"
+#include "ua_align_common.h"
 #include <cmath>
 #include <hip/hip_fp16.h>
 
@@ -465,48 +466,12 @@ align_step_kernel(AlignStepArgs a) {
         }
     }
     ST_MARK(1);
-    // ---- loss statistics (align_loss_kernel, verbatim arithmetic; L staged in LDS) ----
-    const int n = K * K;
-    float mx = -INFINITY;
-    for (int i = tid; i < n; i += nt) { const float l = a.L[i]; Ls[i] = l; mx = fmaxf(mx, l); }
-    mx = block_max_f(mx, sf);
-    ST_MARK(2);
-    if (tid == 0) s_arg = n;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) if (Ls[i] == mx) atomicMin(&s_arg, i);
-    for (int i = tid; i < n; i += nt) P[i] = expf(expf(Ls[i] / mx));
-    __syncthreads();
-    ST_MARK(3);
-    for (int r = tid; r < 2 * K; r += nt) {
-        double s = 0.0;
-        if (r < K) { for (int j = 0; j < K; ++j) s += (double)P[r * K + j]; s1[r] = (float)s; }
-        else { const int cidx = r - K; for (int j = 0; j < K; ++j) s += (double)P[j * K + cidx]; s2[cidx] = (float)s; }
-    }
-    for (int i = tid; i < K; i += nt) dg[i] = P[i * K + i];
-    __syncthreads();
-    ST_MARK(4);
-    double part = 0.0;
-    for (int i = tid; i < K; i += nt) part += (double)(dg[i] / s1[i]) + (double)(dg[i] / s2[i]);
-    const double tot = ua::block_sum(part, sd);
-    ST_MARK(5);
-    if (b == 0 && c == 0 && tid == 0 && a.loss_out) *a.loss_out = (float)(-tot / (double)K);
-    const float invK = 1.f / (float)K;
-    double sacc = 0.0;
-    for (int i = tid; i < n; i += nt) {
-        const int r = (int)((unsigned)i / (unsigned)K), cidx = i - r * K;
-        const float eye = (r == cidx) ? 1.f : 0.f;
-        const float dP = -invK * (eye / s1[r] - dg[r] / (s1[r] * s1[r])) - invK * (eye / s2[cidx] - dg[cidx] / (s2[cidx] * s2[cidx]));
-        const float l = Ls[i];
-        const float E = expf(l / mx);
-        const float dLn = dP * P[i] * E;
-        sacc += (double)dLn * (double)l;
-        P[i] = dLn;
-    }
-    const double S = ua::block_sum(sacc, sd);
-    __syncthreads();
+    // ---- loss statistics: the code of align_loss_kernel (ua_align_common.h), L staged in LDS ----
+    const ua::AlignStats stt = ua::align_stats(a.L, Ls, K, P, s1, s2, dg, sd, sf, &s_arg);
+    if (b == 0 && c == 0 && tid == 0 && a.loss_out) *a.loss_out = (float)(-stt.tot / (double)K);
+    const float mx = stt.mx, corr = stt.corr;
+    const int amax = stt.amax;
     ST_MARK(6);
-    const int amax = s_arg;
-    const float corr = (float)(-S / ((double)mx * (double)mx));
     // ---- backward for row b, columns c*256 .. +255 (align_bwd_kernel with w formed in place) ----
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int r0 = 0; r0 < KM; r0 += 2048) {

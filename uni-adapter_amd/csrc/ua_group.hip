@@ -17,13 +17,25 @@
 
 namespace {
 
+// 64-bit key maximum over the wavefront on DPP (see ua_common.h: the shuffle butterfly costs twelve
+// ds_bpermute round trips per step of the 512-step FPS chain).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)ua::dpp_i<CTRL, ROW_MASK>((int)(unsigned)v);
+    const unsigned hi = (unsigned)ua::dpp_i<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
+    unsigned long long t;
+    t = dpp_u64<0xB1, 0xF>(v); v = t > v ? t : v;
+    t = dpp_u64<0x4E, 0xF>(v); v = t > v ? t : v;
+    t = dpp_u64<0x141, 0xF>(v); v = t > v ? t : v;
+    t = dpp_u64<0x140, 0xF>(v); v = t > v ? t : v;
+    t = dpp_u64<0x142, 0xA>(v); v = t > v ? t : v;          // rows that are not written receive 0 = the identity of max
+    t = dpp_u64<0x143, 0xC>(v); v = t > v ? t : v;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {

@@ -5,6 +5,7 @@
 // :491-521 (fusion).  All of these are K- or K^2-sized (K = classes): latency-bound, so each is
 // one launch of one (or K) workgroups with wavefront reductions and no intermediate HBM traffic.
 #include "ua_common.h"
+#include "ua_align_common.h"
 
 namespace {
 
@@ -42,30 +43,37 @@ __device__ float softmax_entropy_lds(const float* z, float* p, int K, double* sd
 // ------------------------------------------------------------------------------------------
 // get_logits_wrapper, one workgroup of 256 threads.  dynamic LDS: D + 2K floats.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-clip_logits_kernel(const float* __restrict__ feat, const float* __restrict__ text, int K, int D, float scale,
-                   int n_norm, float* __restrict__ fhat, float* __restrict__ logits, float* __restrict__ prob,
-                   float* __restrict__ entropy, int* __restrict__ pred) {
+struct ClipJob {            // one feature vector through :56-57 (and :429 for the augmented copy)
+    const float* feat; int n_norm; float* fhat; float* logits; float* prob; float* entropy; int* pred;
+};
+struct ClipArgs { ClipJob job[2]; const float* text; int K, D; float scale; };
+
+// grid = number of jobs (1 or 2: the sample and its augmented copy in one launch), block 1024.
+__global__ void __launch_bounds__(1024)
+clip_logits_kernel(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ double sd[16];
     __shared__ float sf[16];
+    const ClipJob j = a.job[blockIdx.x];
+    const int K = a.K, D = a.D, nt = blockDim.x;
+    const float scale = a.scale;
     float* f = smem;          // D
     float* z = smem + D;      // K
     float* p = z + K;         // K
-    for (int i = threadIdx.x; i < D; i += 256) f[i] = feat[i];
+    for (int i = threadIdx.x; i < D; i += nt) f[i] = j.feat[i];
     __syncthreads();
-    for (int r = 0; r < n_norm; ++r) {                     // x / x.norm(dim=-1)   :56 (and :429)
+    for (int r = 0; r < j.n_norm; ++r) {                   // x / x.norm(dim=-1)   :56 (and :429)
         double s = 0.0;
-        for (int i = threadIdx.x; i < D; i += 256) s += (double)(f[i] * f[i]);
+        for (int i = threadIdx.x; i < D; i += nt) s += (double)(f[i] * f[i]);
         const float nrm = (float)sqrt(block_sum(s, sd));
-        for (int i = threadIdx.x; i < D; i += 256) f[i] = f[i] / nrm;
+        for (int i = threadIdx.x; i < D; i += nt) f[i] = f[i] / nrm;
         __syncthreads();
     }
-    if (fhat) for (int i = threadIdx.x; i < D; i += 256) fhat[i] = f[i];
-    if (!logits && !prob && !entropy && !pred) return;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = w; k < K; k += 4) {                      // (100*f) @ text^T          :57
-        const float4* t4 = reinterpret_cast<const float4*>(text + (size_t)k * D);
+    if (j.fhat) for (int i = threadIdx.x; i < D; i += nt) j.fhat[i] = f[i];
+    if (!j.logits && !j.prob && !j.entropy && !j.pred) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = nt >> 6;
+    for (int k = w; k < K; k += nw) {                      // (100*f) @ text^T          :57
+        const float4* t4 = reinterpret_cast<const float4*>(a.text + (size_t)k * D);
         double acc = 0.0;
         for (int i = lane; i < D / 4; i += 64) {
             const float4 t = t4[i];
@@ -78,13 +86,13 @@ clip_logits_kernel(const float* __restrict__ feat, const float* __restrict__ tex
     __syncthreads();
     const float h = softmax_entropy_lds(z, p, K, sd, sf);
     __syncthreads();
-    for (int i = threadIdx.x; i < K; i += 256) {
-        if (logits) logits[i] = z[i];
-        if (prob) prob[i] = p[i];
+    for (int i = threadIdx.x; i < K; i += nt) {
+        if (j.logits) j.logits[i] = z[i];
+        if (j.prob) j.prob[i] = p[i];
     }
     if (threadIdx.x == 0) {
-        if (entropy) *entropy = h;
-        if (pred) { int b = 0; for (int i = 1; i < K; ++i) if (z[i] > z[b]) b = i; *pred = b; }
+        if (j.entropy) *j.entropy = h;
+        if (j.pred) { int b = 0; for (int i = 1; i < K; ++i) if (z[i] > z[b]) b = i; *j.pred = b; }
     }
 }
 
@@ -164,43 +172,11 @@ align_loss_kernel(const float* __restrict__ L, const float* __restrict__ joint, 
     float* s2 = s1 + K;              // col sums
     float* dg = s2 + K;              // diagonal
     const int n = K * K, tid = threadIdx.x, nt = blockDim.x;
-    float mx = -INFINITY;
-    for (int i = tid; i < n; i += nt) mx = fmaxf(mx, L[i]);
-    mx = block_max(mx, sf);
-    if (tid == 0) s_arg = n;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) if (L[i] == mx) atomicMin(&s_arg, i);      // first arg-max
-    for (int i = tid; i < n; i += nt) P[i] = expf(expf(L[i] / mx));              // :248-249
-    __syncthreads();
-    for (int r = tid; r < 2 * K; r += nt) {                                      // :251-252
-        double s = 0.0;
-        if (r < K) { for (int j = 0; j < K; ++j) s += (double)P[r * K + j]; s1[r] = (float)s; }
-        else { const int cidx = r - K; for (int j = 0; j < K; ++j) s += (double)P[j * K + cidx]; s2[cidx] = (float)s; }
-    }
-    for (int i = tid; i < K; i += nt) dg[i] = P[i * K + i];
-    __syncthreads();
-    double part = 0.0;
-    for (int i = tid; i < K; i += nt) part += (double)(dg[i] / s1[i]) + (double)(dg[i] / s2[i]);
-    const double tot = block_sum(part, sd);
-    if (tid == 0 && loss_out) *loss_out = (float)(-tot / (double)K);             // :253
+    const ua::AlignStats st = ua::align_stats(L, nullptr, K, P, s1, s2, dg, sd, sf, &s_arg);
+    if (tid == 0 && loss_out) *loss_out = (float)(-st.tot / (double)K);             // :253
     if (!grad_ll) return;
-    // dLoss/dP -> dLoss/dLn ; S = sum dLn * L (for the max() path)
-    const float invK = 1.f / (float)K;
-    double sacc = 0.0;
-    for (int i = tid; i < n; i += nt) {
-        const int r = (int)((unsigned)i / (unsigned)K), cidx = i - r * K;
-        const float eye = (r == cidx) ? 1.f : 0.f;
-        const float dP = -invK * (eye / s1[r] - dg[r] / (s1[r] * s1[r])) - invK * (eye / s2[cidx] - dg[cidx] / (s2[cidx] * s2[cidx]));
-        const float l = L[i];
-        const float E = expf(l / mx);
-        const float dLn = dP * P[i] * E;
-        sacc += (double)dLn * (double)l;
-        P[i] = dLn;                                  // reuse LDS: P now holds dLoss/dLn
-    }
-    const double S = block_sum(sacc, sd);
-    __syncthreads();
-    const int amax = s_arg;
-    const float corr = (float)(-S / ((double)mx * (double)mx));
+    const float mx = st.mx, corr = st.corr;
+    const int amax = st.amax;
     for (int ik = tid; ik < n; ik += nt) {
         float G = P[ik] / mx;
         if (ik == amax) G += corr;
@@ -245,18 +221,39 @@ residual_adam_kernel(const float* __restrict__ text0, float* __restrict__ res, f
 
 }  // namespace
 
+static int launch_clip(const ClipArgs& a, int jobs, void* stream) {
+    if (a.K <= 0 || a.D <= 0) return UA_EINVAL;
+    if (a.D % 4 != 0) return UA_EUNSUPPORTED;
+    const size_t lds = (size_t)(a.D + 2 * a.K) * sizeof(float);
+    if (lds > 150 * 1024) return UA_EUNSUPPORTED;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(clip_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return UA_ELAUNCH;
+    hipLaunchKernelGGL(clip_logits_kernel, dim3(jobs), dim3(1024), lds, ua::as_stream(stream), a);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
 extern "C" int ua_clip_logits(const float* feat, const float* text, int32_t K, int32_t D, float scale,
                               int32_t n_normalize, float* fhat, float* logits, float* prob, float* entropy,
                               int32_t* pred, void* stream) {
     UA_CHECK_PTR(feat); UA_CHECK_PTR(text); UA_CHECK_ALIGN16(text);
-    if (K <= 0 || D <= 0 || n_normalize < 0) return UA_EINVAL;
-    if (D % 4 != 0) return UA_EUNSUPPORTED;
-    const size_t lds = (size_t)(D + 2 * K) * sizeof(float);
-    if (lds > 150 * 1024) return UA_EUNSUPPORTED;
-    hipLaunchKernelGGL(clip_logits_kernel, dim3(1), dim3(256), lds, ua::as_stream(stream),
-                       feat, text, K, D, scale, n_normalize, fhat, logits, prob, entropy, pred);
-    UA_LAUNCH_CHECK();
-    return UA_OK;
+    if (n_normalize < 0) return UA_EINVAL;
+    ClipArgs a{};
+    a.job[0] = ClipJob{feat, n_normalize, fhat, logits, prob, entropy, pred};
+    a.text = text; a.K = K; a.D = D; a.scale = scale;
+    return launch_clip(a, 1, stream);
+}
+
+extern "C" int ua_clip_logits_pair(const float* feat, const float* feat_aug, const float* text, int32_t K, int32_t D,
+                                   float scale, float* fhat, float* faug, float* logits, float* prob, void* stream) {
+    UA_CHECK_PTR(feat); UA_CHECK_PTR(feat_aug); UA_CHECK_PTR(text); UA_CHECK_PTR(fhat); UA_CHECK_PTR(faug);
+    UA_CHECK_ALIGN16(text);
+    ClipArgs a{};
+    a.job[0] = ClipJob{feat, 1, fhat, logits, prob, nullptr, nullptr};          // Uni_Adapter.py:406
+    a.job[1] = ClipJob{feat_aug, 2, faug, nullptr, nullptr, nullptr, nullptr};  // :424, :429 (normalised twice)
+    a.text = text; a.K = K; a.D = D; a.scale = scale;
+    return launch_clip(a, 2, stream);
 }
 
 extern "C" int ua_fuse_logits(const float* clip_logits, const float* dota_logits, const float* c,

@@ -22,10 +22,8 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
         const float* f = feats + (size_t)j * 2 * D;
         const float* fa = f + D;
         int rc;
-        if ((rc = ua_clip_logits(f, text, K, D, s->logit_scale, 1, s->fhat, s->clip_logits, s->prob, nullptr,
-                                 nullptr, stream))) return rc;                  // :406
-        if ((rc = ua_clip_logits(fa, text, K, D, s->logit_scale, 2, s->faug, nullptr, nullptr, nullptr,
-                                 nullptr, stream))) return rc;                  // :424, :429
+        if ((rc = ua_clip_logits_pair(f, fa, text, K, D, s->logit_scale, s->fhat, s->faug, s->clip_logits, s->prob,
+                                      stream))) return rc;               // :406, :424, :429
         if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
                                     s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
         if (s->res_learning && sample_index0 + j > 0) {                         // :444-476
