@@ -86,6 +86,15 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_probe(kernel):
+    """Counters of the committed PMC passes for one kernel (profiles/r01_f_pmc.json; probe shape in DESIGN.md section 7), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_f_pmc.json')))[kernel]
+        return {k: d[k] for k in ('us_per_launch_under_pmc', 'traffic_bytes', 'mfma_busy_frac', 'effective_clock_GHz', 'l2_hit_rate') if k in d}
+    except Exception:
+        return None
+
+
 def similarity_roofline(dev):
     """HBM roofline of the similarity kernel at configs[4] size (state 2 x 268 MB > Infinity Cache)."""
     from uni_adapter_amd import lib
@@ -233,6 +242,9 @@ def main():
             roof = {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(tfl / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_f32_mfma_kernel',
                     'mfma_dtype': 'f32'}
+        # `traffic` stays null: the launches of a step have 7 different shapes; the PMC passes were taken on the
+        # qkv shape (16416 x 3072 x 1024) alone and are attached as `pmc_probe`
+        roof['pmc_probe'] = pmc_probe('gemm_split_kernel<16>' if dom == 'split' else 'gemm_f32_mfma_kernel')
         roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
                      'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt, 4)})
