@@ -49,6 +49,28 @@ def test_bad_arguments_return_codes_without_gpu():
         lib.call('ua_gmm_loglik', p16 + 4, p16, p16, p16, 1, 4, 4, 256, 1e-4, None, None, None, None)
     with pytest.raises(RuntimeError, match='aligned'):      # K % 4 != 0
         lib.call('ua_gemm', p16, 8, p16, 8, p16, 8, 4, 4, 6, None, None)
+    # fused residual step: K above the LDS envelope, D not a multiple of 256, step 0, missing tickets
+    args = [p16] * 10
+    with pytest.raises(RuntimeError, match='envelope'):
+        lib.call('ua_align_step', *args, 129, 8, 1024, 1, 1e-3, 0.9, 0.999, 1e-8, None, None, p16, p16, None)
+    with pytest.raises(RuntimeError, match='envelope'):
+        lib.call('ua_align_step', *args, 40, 8, 1000, 1, 1e-3, 0.9, 0.999, 1e-8, None, None, p16, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_align_step', *args, 40, 8, 1024, 0, 1e-3, 0.9, 0.999, 1e-8, None, None, p16, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_align_step', *args, 40, 8, 1024, 1, 1e-3, 0.9, 0.999, 1e-8, None, None, p16, None, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):          # augmented copy missing
+        lib.call('ua_clip_logits_pair', p16, None, p16, 40, 1024, 100.0, p16, p16, None, None, None)
+    with pytest.raises(RuntimeError, match='envelope'):                  # D % 4
+        lib.call('ua_clip_logits_pair', p16, p16, p16, 40, 1022, 100.0, p16, p16, None, None, None)
+    # split GEMM: K must be a multiple of 32, scales positive; rowgroup_add groups are multiples of 32 rows
+    with pytest.raises(RuntimeError, match='aligned'):
+        lib.call('ua_gemm_split', p16, 48, 1.0, p16, 48, 1.0, p16, 64, 64, 64, 48, None, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gemm_split', p16, 64, 0.0, p16, 64, 1.0, p16, 64, 64, 64, 64, None, None)
+    e = lib.GemmEpilogue(); e.rowgroup_add = p16; e.ldg = 64; e.group_rows = 48
+    with pytest.raises(RuntimeError, match='envelope'):
+        lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 96, 64, 64, ctypes.byref(e), None)
 
 
 def test_cpu_tensors_are_rejected_loudly():
