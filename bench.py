@@ -265,7 +265,9 @@ def main():
                    'samples_per_rank_per_step': n_local, 'global_samples_per_step': n_global, 'encoder_depth': a.depth,
                    'gemm_mode': main_mode,
                    'replay_overlap': bool(a.overlap),
-                   'parallelism': f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step'},
+                   'parallelism': (f'sample-sharded encoder x{world}, in-order cache replay on rank 0 (its encoder share reduced to balance), '
+                                   f'1 all_gather/step' if world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'owner' else
+                                   f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step')},
         'roofline': res['roofline'],
     }
     if a.both_modes:

@@ -1,5 +1,6 @@
-"""world_size-2 gloo (CPU) tests of the N>1 path: sample sharding, the one all_gather per chunk
-and the replicated in-order cache replay give results identical to the single-process stream."""
+"""world_size-2/3 gloo (CPU) tests of the N>1 path: sample sharding, the one all_gather per chunk
+and the in-order cache replay (replicated on every rank, or on the owner rank only with a reduced
+encoder share for it) give results identical to the single-process stream."""
 import os
 import socket
 
@@ -76,3 +77,70 @@ def test_shard_indices_partition():
         for w in (1, 2, 3, 8):
             allidx = torch.cat([shard_indices(n, r, w) for r in range(w)]).sort()[0]
             assert torch.equal(allidx, torch.arange(n))
+
+
+def _worker_owner(rank, world, port, n, chunk, rho, out):
+    """'owner' mode: contiguous, uneven shares; rank 0 alone replays; results broadcast from it."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import broadcast_from_owner, gather_feature_blocks, shard_block, shard_counts
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(0)
+    K, D = 6, 64
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    data = torch.randn(n, 5, 3, generator=g)
+    lab = torch.randint(0, K, (n,), generator=g)
+    s = O.TtaStream(text, O.TtaConfig(num_modes=2, res_learning=False)) if rank == 0 else None
+    finals = []
+    for c0 in range(0, n, chunk):
+        nn_ = min(chunk, n - c0)
+        mine = shard_block(nn_, rank, world, rho)
+        assert len(mine) == shard_counts(nn_, world, rho)[rank]
+        x = data[c0:c0 + nn_][mine]
+        f = torch.stack([text[lab[c0:c0 + nn_][mine]] + 0.05 * torch.cos(x.sum((1, 2)))[:, None] * torch.ones(D),
+                         text[lab[c0:c0 + nn_][mine]] + 0.05 * torch.sin(x.sum((1, 2)))[:, None] * torch.ones(D)], 1) \
+            if len(mine) else torch.zeros(0, 2, D)
+        feats = gather_feature_blocks(f, nn_, rank, world, None, rho)
+        assert feats.shape == (nn_, 2, D)
+        if rank == 0:
+            for j in range(nn_):
+                finals.append(s.step(feats[j, 0:1], feats[j, 1:2])[2])
+    res = torch.cat(finals) if rank == 0 else torch.zeros(n, K)
+    if world > 1:
+        broadcast_from_owner(res)
+    if rank == world - 1:                       # a non-owner rank ends up with the owner's results
+        np.save(out, res.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,rho', [(2, 0.14), (3, 0.14), (2, 2.0)])
+def test_owner_replay_equals_single_process(tmp_path, world, rho):
+    """rho = 2.0 drives the owner's encoder share to zero (the W = 8 situation): rank 0 only replays."""
+    n, chunk = 11, 5
+    outs = []
+    for w in (1, world):
+        out = str(tmp_path / f'o{w}.npy')
+        mp.spawn(_worker_owner, args=(w, _free_port(), n, chunk, rho, out), nprocs=w, join=True)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_shard_counts_balance_rule():
+    import sys
+    sys.path.insert(0, ROOT)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import shard_block, shard_counts
+    assert shard_counts(31, 1) == [31]
+    for n in (1, 5, 62, 124, 248):
+        for w in (2, 3, 4, 8):
+            c = shard_counts(n, w)
+            assert sum(c) == n and len(c) == w and min(c) >= 0
+            assert max(c[1:]) - min(c[1:]) <= 1                       # the encoders are balanced among themselves
+            assert c[0] <= min(c[1:]) + 1                             # the owner never encodes more than an encoder rank
+            assert torch.equal(torch.cat([shard_block(n, r, w) for r in range(w)]), torch.arange(n))
+    # the rule of stream.py: x0 = (n/W) max(0, 1 - rho (W-1))
+    assert shard_counts(62, 2, rho=0.14)[0] == 27 and shard_counts(124, 4, rho=0.14)[0] == 18 and shard_counts(248, 8, rho=0.14)[0] == 1
+    assert shard_counts(248, 8)[0] == 0 and shard_counts(248, 8, rho=0.2)[0] == 0

@@ -195,3 +195,59 @@ def test_replay_overlap_gives_identical_results(golden_dir):
         outs.append((torch.cat([r[0] for r in res]).cpu(), torch.cat([r[1] for r in res]).cpu(), eng.accuracy(), eng.residuals.res.cpu().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2] and torch.equal(outs[0][3], outs[1][3])
+
+
+def _owner_mode_worker(rank, world, port, out):
+    """One rank of a 2-process job sharing cuda:0 (gloo): TtaEngine in 'owner' replay mode."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), UA_REPLAY_MODE='owner')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    finals, acc = _run_small_stream(TtaEngine, create_uni3d_from_state_dict, synthetic)
+    if rank == 0:
+        torch.save({'finals': finals.cpu(), 'acc': acc}, out)
+    else:
+        torch.save({'acc': acc}, out + '.r1')
+    dist.destroy_process_group()
+
+
+def _run_small_stream(TtaEngine, create, synthetic):
+    K, D, n, chunk = 10, 256, 10, 5
+    sd = synthetic.uni3d_state_dict(1, trans_dim=128, embed_dim=D, depth=1, device='cuda')
+    model = create(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    text = synthetic.text_bank(K, D, 2)
+    xyz, rgb = synthetic.point_clouds(n, 1024, 3, device='cuda')
+    noise = torch.randn(n, 1024, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    tgt = torch.arange(n, device='cuda') % K
+    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 2, res_learning=True, chunk=chunk,
+                    device=torch.device('cuda'), replay_cost_ratio=0.3)
+    outs = []
+    for c0 in range(0, n, chunk):
+        f, _, _ = eng.process_chunk(xyz[c0:c0 + chunk], rgb[c0:c0 + chunk], tgt[c0:c0 + chunk], noise[c0:c0 + chunk])
+        outs.append(f)
+    return torch.cat(outs), eng.accuracy()
+
+
+def test_owner_replay_mode_two_ranks_on_one_gpu(tmp_path):
+    """W = 2 with the cache replay on rank 0 only (uneven encoder shares, one all_gather per chunk, accuracy
+    broadcast) reproduces the single-process stream bit for bit; both ranks report the same accuracy."""
+    import socket
+    import torch.multiprocessing as mp
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    ref, ref_acc = _run_small_stream(TtaEngine, create_uni3d_from_state_dict, synthetic)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'owner.pt')
+    mp.spawn(_owner_mode_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert torch.equal(got['finals'], ref.cpu())
+    assert got['acc'] == ref_acc and torch.load(out + '.r1', weights_only=True)['acc'] == ref_acc

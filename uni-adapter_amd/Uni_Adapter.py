@@ -23,7 +23,8 @@ import torch.nn.functional as F
 
 from . import lib
 from .dota_mixture import DOTA_mix
-from .stream import gather_features, shard_indices
+from .stream import (REPLAY_COST_RATIO, broadcast_from_owner, gather_feature_blocks, gather_features, shard_block,
+                     shard_indices)
 
 LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
 NOISE_STD = 0.05             # Uni_Adapter.py:420
@@ -114,7 +115,8 @@ class TtaEngine:
     test_zeroshot_3d_core (the reference rebuilds all state per corruption, Uni_Adapter.py:336-352)."""
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
-                 log_alignment_every=0, dist_group=None, composite=True, overlap=False):
+                 log_alignment_every=0, dist_group=None, composite=True, overlap=False, replay_mode=None,
+                 replay_cost_ratio=REPLAY_COST_RATIO):
         self.model = model
         self.composite = bool(composite) and not log_alignment_every
         # overlap=True: the in-order cache replay of chunk c runs on a second HIP stream while the
@@ -138,6 +140,13 @@ class TtaEngine:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(dist_group)
             self.rank = torch.distributed.get_rank(dist_group)
+        # where the sequential cache replay runs when W > 1 (stream.py): 'owner' = rank 0 only, with a
+        # smaller encoder share for rank 0; 'replicated' = every rank replays everything
+        self.replay_mode = replay_mode or os.environ.get('UA_REPLAY_MODE', 'owner')
+        if self.replay_mode not in ('owner', 'replicated'):
+            raise ValueError(f"replay_mode must be 'owner' or 'replicated', got {self.replay_mode!r}")
+        self.replay_cost_ratio = float(replay_cost_ratio)
+        self.replays = self.world == 1 or self.replay_mode == 'replicated' or self.rank == 0
         K, D, M, dev = self.K, self.D, self.M, self.dev
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
         self.fh, self.fa = e(1, D), e(1, D)
@@ -172,7 +181,8 @@ class TtaEngine:
         """pc, rgb (n,N,3); noise (n,N,3) = the randn draw of Uni_Adapter.py:421.  Returns
         features (n,2,D): [:,0] original, [:,1] augmented cloud."""
         n = pc.shape[0]
-        mine = shard_indices(n, self.rank, self.world)
+        owner_mode = self.world > 1 and self.replay_mode == 'owner'
+        mine = shard_block(n, self.rank, self.world, self.replay_cost_ratio) if owner_mode else shard_indices(n, self.rank, self.world)
         D = self.D
         if len(mine):
             p, c, z = pc[mine], rgb[mine], noise[mine]
@@ -181,8 +191,9 @@ class TtaEngine:
         else:
             local = torch.zeros(0, 2, D, device=self.dev)
         # one exchange per chunk (RCCL all_gather over xGMI); a no-op at world 1
-        feats = gather_features(local, n, self.rank, self.world, self.group)
-        return feats
+        if owner_mode:
+            return gather_feature_blocks(local, n, self.rank, self.world, self.group, self.replay_cost_ratio)
+        return gather_features(local, n, self.rank, self.world, self.group)
 
     # -- sequential cache step of ONE sample ----------------------------------------------
     def cache_step(self, feat, feat_aug, target, out_final, out_rank, out_pred):
@@ -244,6 +255,13 @@ class TtaEngine:
         ranks = torch.full((n,), -1, device=self.dev, dtype=torch.int32)
         preds = torch.empty(n, device=self.dev, dtype=torch.int32)
         tgt = target.to(self.dev, torch.int32) if target is not None else None
+        if not self.replays:
+            # 'owner' mode, rank > 0: this rank only encodes; the state and the results live on rank 0
+            if self.res_learning:
+                self.residuals.step += RES_STEPS * (n - (1 if self.i == 0 else 0))
+            self.i += n
+            self.mode_dota_model.t += 2 * n
+            return final.zero_(), ranks, preds.fill_(-1)
         if self.composite:
             # one host call enqueues the whole in-order replay of the chunk (csrc/ua_tta.hip)
             import ctypes
@@ -318,6 +336,10 @@ class TtaEngine:
     def accuracy(self):
         """{'acc1','acc3','acc5'} in percent over everything processed so far (host sync)."""
         self.synchronize()
+        if self.world > 1 and self.replay_mode == 'owner':
+            t = torch.cat([self.correct, torch.tensor([self.count], device=self.dev, dtype=torch.int64)])
+            broadcast_from_owner(t, self.group)
+            self.correct.copy_(t[:3]); self.count = int(t[3])
         c = self.correct.tolist()
         d = max(1, self.count)
         return {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}

@@ -8,9 +8,75 @@ The reference has no working multi-process path (utils/distributed.py:81-98 read
 its only live collective, the all-reduce of accuracies (Uni_Adapter.py:582), is unnecessary here
 because every rank holds every prediction.
 
+Two ways to place the sequential part:
+  * 'replicated': every rank replays all W*n samples of a step on its own replica of the state.  The
+    replay then competes with the encoder on EVERY GPU (measured on one MI355X standing in for a rank
+    of a W-GPU job, tools/emulate_scaling.py: 92 / 72 / 52 % weak-scaling efficiency at W = 2 / 4 / 8).
+  * 'owner' (default for W > 1): rank 0 alone holds the state and replays; the other ranks only encode,
+    and rank 0 gets a correspondingly smaller encoder share,  x0 = (n/W) * max(0, 1 - rho*(W-1)),
+    rho = (marginal replay ms per sample) / (encoder ms per sample) ~ 0.15 on MI355X, so that all ranks
+    finish a step together (W = 8: rank 0 encodes nothing and replays 248 samples in 74 ms while seven
+    ranks encode 35-36 samples each).  Results live on rank 0; accuracies are broadcast at the end.
+Both give results identical to the single-process stream.
+
 Device-agnostic on purpose (no HIP calls), so the N>1 logic is covered by world_size-2 gloo tests.
 """
 import torch
+
+REPLAY_COST_RATIO = 0.15        # rho: see above (DESIGN.md section 6)
+
+
+def shard_counts(n, world, rho=REPLAY_COST_RATIO):
+    """'owner' mode: samples of an n-sample chunk encoded by each rank (contiguous blocks in rank order)."""
+    if world == 1:
+        return [n]
+    x0 = int(round((n / world) * max(0.0, 1.0 - rho * (world - 1))))
+    x0 = min(max(x0, 0), n)
+    rest, others = n - x0, world - 1
+    return [x0] + [rest // others + (1 if r < rest % others else 0) for r in range(others)]
+
+
+def shard_block(n, rank, world, rho=REPLAY_COST_RATIO):
+    """Indices of `rank`'s contiguous block under shard_counts."""
+    counts = shard_counts(n, world, rho)
+    start = sum(counts[:rank])
+    return torch.arange(start, start + counts[rank])
+
+
+def gather_feature_blocks(local, n, rank, world, group=None, rho=REPLAY_COST_RATIO):
+    """local: features of shard_block(n, rank, world).  Returns the (n, ...) features of the chunk in
+    stream order (one all_gather of blocks padded to the largest share)."""
+    if world == 1:
+        return local
+    counts = shard_counts(n, world, rho)
+    per = max(counts)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = _all_gather(pad, world, group)
+    return torch.cat([parts[r][:counts[r]] for r in range(world)], 0)
+
+
+def _all_gather(pad, world, group):
+    if pad.is_cuda and torch.distributed.get_backend(group) == 'gloo':
+        # rehearsal path (several ranks sharing one GPU, gloo): stage through host memory
+        host = pad.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        torch.distributed.all_gather(parts, host, group=group)
+        return [p.to(pad.device) for p in parts]
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    torch.distributed.all_gather(parts, pad, group=group)       # RCCL over xGMI on a multi-GPU node
+    return parts
+
+
+def broadcast_from_owner(t, group=None):
+    """In-place broadcast of a small tensor from rank 0 (gloo rehearsals stage CUDA tensors through the host)."""
+    if t.is_cuda and torch.distributed.get_backend(group) == 'gloo':
+        h = t.cpu()
+        torch.distributed.broadcast(h, src=0, group=group)
+        t.copy_(h)
+    else:
+        torch.distributed.broadcast(t, src=0, group=group)
+    return t
 
 
 def shard_indices(n, rank, world):
@@ -32,15 +98,6 @@ def gather_features(local, n, rank, world, group=None):
     per = (n + world - 1) // world
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    if pad.is_cuda and torch.distributed.get_backend(group) == 'gloo':
-        # rehearsal path (several ranks sharing one GPU, gloo): stage through host memory
-        host = pad.cpu()
-        parts = [torch.empty_like(host) for _ in range(world)]
-        torch.distributed.all_gather(parts, host, group=group)
-        stacked = torch.stack(parts, 0).to(pad.device)
-    else:
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        torch.distributed.all_gather(parts, pad, group=group)   # RCCL over xGMI on a multi-GPU node
-        stacked = torch.stack(parts, 0)                   # (W, per, ...)
+    stacked = torch.stack(_all_gather(pad, world, group), 0)      # (W, per, ...)
     j = torch.arange(n, device=local.device)
     return stacked[j % world, j // world]
