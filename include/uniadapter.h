@@ -170,6 +170,14 @@ int ua_knn_group(const float* xyz, const float* rgb, const float* centers,
                  int32_t B, int32_t N, int32_t G, int32_t S,
                  float* feat, int32_t ldf, int32_t* idx, void* stream);
 
+/* Ball query + gather of the OpenShape PPAT set-abstraction layer (models/openshape/pointnet_util.py:
+ * 89-146): per centre the first S points in index order with square_distance <= radius^2, padded with
+ * the first hit; feat row = [p - centre (3) | point_feat[p] (F) | zeros up to ldf].  xyz (B,N,3),
+ * point_feat (B,N,F), centers (B,G,3); feat (B*G*S, ldf), ldf >= 3+F; idx (B,G,S) optional.  N <= 8192. */
+int ua_ball_group(const float* xyz, const float* point_feat, const float* centers,
+                  int32_t B, int32_t N, int32_t G, int32_t S, int32_t F, float radius,
+                  float* feat, int32_t ldf, int32_t* idx, void* stream);
+
 /* Epilogue of ua_gemm; all pointers optional (NULL = skipped).  Order of operations:
  *   v = acc + (bias[n] + rowgroup_add[m / group_rows, n])     (group_rows: a multiple of 32)
  *   v = v*scale[n] + shift[n]                (eval BatchNorm, models/point_encoder.py:135,141)

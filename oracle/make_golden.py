@@ -346,6 +346,34 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'g8_ulip.npz'), xyz=uxyz.numpy(), center_idx=ucidx.numpy(), weights_seed=np.int64(9),
                         concat=ucat.numpy(), embed=uemb.numpy())
     print('g8 ulip', uemb.shape, uemb[0, :3])
+    # ---- G9: OpenShape PPAT parts that run without torch_redstone (models/openshape/pointnet_util.py, ppta.py:9-81) ----
+    from einops import rearrange
+    feats9 = torch.cat([xyz, rgb], -1)                                  # in_channel 6 = xyz + rgb
+    G9, S9, R9, H9 = 128, 64, 0.2, 8
+    cidx9 = O.fps(xyz, G9, start=1, skip_origin_eps=-1.0)
+    pu = {'torch': torch, 'nn': nn, 'F': F, 'farthest_point_sample': lambda xyz_, npoint: cidx9}    # FPS start is random in the reference (:75)
+    _exec_defs(os.path.join(REF, 'models', 'openshape', 'pointnet_util.py'),
+               ['square_distance', 'index_points', 'query_ball_point', 'sample_and_group', 'PointNetSetAbstraction'], pu)
+    sd9 = O.make_ppat_state_dict(21, depth=2)
+    sa9 = pu['PointNetSetAbstraction'](npoint=G9, radius=R9, nsample=S9, in_channel=9, mlp=[64, 64, 256], group_all=False)
+    sa9.load_state_dict({k[len('ppat.sa.'):]: v for k, v in sd9.items() if k.startswith('ppat.sa.')}, strict=False)
+    sa9.eval()
+    with torch.no_grad():
+        nx9, nf9 = sa9(xyz.transpose(1, 2).contiguous(), feats9.transpose(1, 2).contiguous())
+        ball9 = pu['query_ball_point'](R9, S9, xyz, xyz[torch.arange(2)[:, None], cidx9])
+    pt9 = {'torch': torch, 'nn': nn, 'rearrange': rearrange}
+    _exec_defs(os.path.join(REF, 'models', 'openshape', 'ppta.py'), ['PreNorm', 'FeedForward', 'Attention', 'Transformer'], pt9)
+    tr9 = pt9['Transformer'](512, 2, H9, 64, 1536, 0.0, False)
+    tr9.load_state_dict({k[len('ppat.transformer.'):]: v for k, v in sd9.items() if k.startswith('ppat.transformer.')}, strict=True)
+    tr9.eval()
+    tok9 = O.ppat_encode(xyz, feats9, sd9, G9, R9, S9, H9, center_idx=cidx9, return_parts=True)[3]
+    with torch.no_grad():
+        y9 = tr9(tok9, None)
+    np.savez_compressed(os.path.join(OUT, 'g9_ppat.npz'), xyz=xyz.numpy(), feats=feats9.numpy(), center_idx=cidx9.numpy(),
+                        weights_seed=np.int64(21), ball_idx=ball9.numpy().astype(np.int32),
+                        sa_centers=nx9.transpose(1, 2).contiguous().numpy(), sa_features=nf9.transpose(1, 2).contiguous().numpy(),
+                        tokens_in=tok9.numpy(), tokens_out=y9.numpy())
+    print('g9 ppat', y9.shape)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

@@ -561,6 +561,112 @@ def make_ulip_state_dict(seed: int, trans_dim: int = 384, depth: int = 12, enc_d
 
 
 # ======================================================================================
+# F1  OpenShape PPAT encoder (models/openshape/ppta.py, pointnet_util.py)
+# ======================================================================================
+def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    """pointnet_util.py:89-110: first `nsample` indices (ascending) with square_distance <= r^2, padded with the first."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    group_idx = torch.arange(N).view(1, 1, N).repeat(B, S, 1)
+    sq = square_distance(new_xyz, xyz)
+    group_idx[sq > radius ** 2] = N
+    group_idx = group_idx.sort(dim=-1)[0][:, :, :nsample]
+    first = group_idx[..., :1].repeat(1, 1, nsample)
+    mask = group_idx == N
+    group_idx[mask] = first[mask]
+    return group_idx
+
+
+def ppat_set_abstraction(xyz: torch.Tensor, feats: torch.Tensor, sd: Dict[str, torch.Tensor], center_idx: torch.Tensor,
+                         radius: float, nsample: int, prefix: str = 'ppat.sa.', bn_eps: float = 1e-5):
+    """pointnet_util.py:113-146,184-211 (eval BatchNorm).  xyz (B,N,3), feats (B,N,F) -> centres (B,G,3), features (B,G,C_out)."""
+    B = xyz.shape[0]
+    ar = torch.arange(B)[:, None]
+    new_xyz = xyz[ar, center_idx]
+    idx = ball_query(radius, nsample, xyz, new_xyz)
+    grouped = xyz[ar[:, :, None], idx] - new_xyz[:, :, None, :]
+    x = torch.cat([grouped, feats[ar[:, :, None], idx]], -1)                          # (B,G,S,3+F)
+    i = 0
+    while prefix + f'mlp_convs.{i}.weight' in sd:
+        w = sd[prefix + f'mlp_convs.{i}.weight'].reshape(sd[prefix + f'mlp_convs.{i}.weight'].shape[0], -1)
+        x = x @ w.t() + sd[prefix + f'mlp_convs.{i}.bias']
+        g, b_ = sd[prefix + f'mlp_bns.{i}.weight'], sd[prefix + f'mlp_bns.{i}.bias']
+        m, v = sd[prefix + f'mlp_bns.{i}.running_mean'], sd[prefix + f'mlp_bns.{i}.running_var']
+        x = F.relu((x - m) / torch.sqrt(v + bn_eps) * g + b_)
+        i += 1
+    return new_xyz, x.max(2)[0], idx
+
+
+def ppat_transformer(x: torch.Tensor, sd: Dict[str, torch.Tensor], heads: int, prefix: str = 'ppat.transformer.',
+                     ln_eps: float = 1e-5) -> torch.Tensor:
+    """ppta.py:9-81 (PreNorm / Attention without rel_pe / FeedForward, dropout 0)."""
+    B, T, C = x.shape
+    l = 0
+    while prefix + f'layers.{l}.0.norm.weight' in sd:
+        P = prefix + f'layers.{l}.'
+        h = _ln(x, sd[P + '0.norm.weight'], sd[P + '0.norm.bias'], ln_eps)
+        qkv = h @ sd[P + '0.fn.to_qkv.weight'].t()
+        inner = qkv.shape[-1] // 3
+        hd = inner // heads
+        q, k, v = (t.reshape(B, T, heads, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        att = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(B, T, inner)
+        x = o @ sd[P + '0.fn.to_out.0.weight'].t() + sd[P + '0.fn.to_out.0.bias'] + x
+        h = _ln(x, sd[P + '1.norm.weight'], sd[P + '1.norm.bias'], ln_eps)
+        h = F.gelu(h @ sd[P + '1.fn.net.0.weight'].t() + sd[P + '1.fn.net.0.bias'])
+        x = h @ sd[P + '1.fn.net.3.weight'].t() + sd[P + '1.fn.net.3.bias'] + x
+        l += 1
+    return x
+
+
+def ppat_encode(xyz: torch.Tensor, feats: torch.Tensor, sd: Dict[str, torch.Tensor], patches: int, radius: float, nsample: int,
+                heads: int, center_idx: Optional[torch.Tensor] = None, fps_start: int = 0, return_parts: bool = False):
+    """ppta.py:113-147 (`Projected(PointPatchTransformer)`, cache_type 'global'): SA -> lift (Conv1d + LayerNorm) ->
+    [cls, tokens] -> transformer -> proj(cls).  The three glue lines that need torch_redstone (:94,:119-120) are
+    restated from their meaning (permute, concatenate) - the reference module itself cannot be constructed here."""
+    if center_idx is None:
+        center_idx = fps(xyz, patches, start=fps_start, skip_origin_eps=-1.0)
+    cen, sa, _ = ppat_set_abstraction(xyz, feats, sd, center_idx, radius, nsample)
+    w = sd['ppat.lift.0.weight'].reshape(sd['ppat.lift.0.weight'].shape[0], -1)           # Conv1d(sa_dim+3, dim, 1) on cat[centroids, feature]
+    x = torch.cat([cen, sa], -1) @ w.t() + sd['ppat.lift.0.bias']
+    x = _ln(x, sd['ppat.lift.2.weight'], sd['ppat.lift.2.bias'], 1e-5)
+    tok = torch.cat([sd['ppat.cls_token'].expand(x.shape[0], 1, -1), x], 1)
+    y = ppat_transformer(tok, sd, heads)
+    out = y[:, 0] @ sd['proj.weight'].t() + sd['proj.bias']
+    return (out, cen, sa, tok, y) if return_parts else out
+
+
+def make_ppat_state_dict(seed: int, dim: int = 512, depth: int = 12, heads: int = 8, mlp_dim: int = 1536, sa_dim: int = 256,
+                         in_dim: int = 6, out_dim: int = 1280, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights in the key layout of `Projected(PointPatchTransformer(...), nn.Linear)` (ppta.py:83-147)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, sc=0.02: (torch.randn(*s, generator=g) * sc).to(dtype)
+    sd: Dict[str, torch.Tensor] = {}
+    last = in_dim + 3
+    for i, c in enumerate([64, 64, sa_dim]):
+        sd[f'ppat.sa.mlp_convs.{i}.weight'] = rn(c, last, 1, 1, sc=1 / math.sqrt(last)); sd[f'ppat.sa.mlp_convs.{i}.bias'] = rn(c)
+        sd[f'ppat.sa.mlp_bns.{i}.weight'] = (1 + 0.1 * torch.randn(c, generator=g)).to(dtype)
+        sd[f'ppat.sa.mlp_bns.{i}.bias'] = rn(c, sc=0.1)
+        sd[f'ppat.sa.mlp_bns.{i}.running_mean'] = rn(c, sc=0.1)
+        sd[f'ppat.sa.mlp_bns.{i}.running_var'] = (1 + 0.2 * torch.rand(c, generator=g)).to(dtype)
+        last = c
+    sd['ppat.lift.0.weight'] = rn(dim, sa_dim + 3, 1, sc=1 / math.sqrt(sa_dim + 3)); sd['ppat.lift.0.bias'] = rn(dim)
+    sd['ppat.lift.2.weight'] = (1 + 0.05 * torch.randn(dim, generator=g)).to(dtype); sd['ppat.lift.2.bias'] = rn(dim, sc=0.05)
+    sd['ppat.cls_token'] = rn(dim, sc=1.0)
+    inner = heads * 64
+    for l in range(depth):
+        P = f'ppat.transformer.layers.{l}.'
+        for j in (0, 1):
+            sd[P + f'{j}.norm.weight'] = (1 + 0.05 * torch.randn(dim, generator=g)).to(dtype); sd[P + f'{j}.norm.bias'] = rn(dim, sc=0.05)
+        sd[P + '0.fn.to_qkv.weight'] = rn(3 * inner, dim, sc=1 / math.sqrt(dim))
+        sd[P + '0.fn.to_out.0.weight'] = rn(dim, inner, sc=1 / math.sqrt(inner)); sd[P + '0.fn.to_out.0.bias'] = rn(dim)
+        sd[P + '1.fn.net.0.weight'] = rn(mlp_dim, dim, sc=1 / math.sqrt(dim)); sd[P + '1.fn.net.0.bias'] = rn(mlp_dim)
+        sd[P + '1.fn.net.3.weight'] = rn(dim, mlp_dim, sc=1 / math.sqrt(mlp_dim)); sd[P + '1.fn.net.3.bias'] = rn(dim)
+    sd['proj.weight'] = rn(out_dim, dim, sc=1 / math.sqrt(dim)); sd['proj.bias'] = rn(out_dim)
+    return sd
+
+
+# ======================================================================================
 # A14  per-sample loop (cache part; encoder outputs are inputs)
 # ======================================================================================
 @dataclass

@@ -139,3 +139,69 @@ def test_ulip_encoder_full_depth_and_logits_wrapper(precision):
     rz = 100.0 * torch.nn.functional.normalize(ref[:1], dim=1) @ text.t()
     assert (z.cpu() - rz).abs().max().item() < 1e-3
     assert pred == int(rz.argmax())
+
+
+# ---------------------------------------------------------------- OpenShape PPAT variant (section 8 F1)
+def test_ball_group_kernel_vs_reference_fixture():
+    """ua_ball_group against the reference's own query_ball_point / sample_and_group output (g9)."""
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd import lib
+    g = _golden('g9_ppat.npz')
+    xyz, feats = torch.from_numpy(g['xyz']).cuda(), torch.from_numpy(g['feats']).cuda()
+    cidx = torch.from_numpy(g['center_idx'])
+    B, N, _ = xyz.shape; G, S, Fc = cidx.shape[1], 64, feats.shape[2]
+    centers = xyz[torch.arange(B)[:, None], cidx.cuda()].contiguous()
+    out = torch.full((B * G * S, 12), 7.0, device='cuda'); idx = torch.empty(B, G, S, dtype=torch.int32, device='cuda')
+    lib.call('ua_ball_group', lib.ptr(xyz), lib.ptr(feats), lib.ptr(centers), B, N, G, S, Fc, 0.2, lib.ptr(out), 12, lib.ptr(idx, torch.int32),
+             lib.stream_ptr())
+    want = torch.from_numpy(g['ball_idx']).long()
+    got = idx.cpu().long()
+    same = (got == want).all(-1)
+    assert same.float().mean() >= 0.995, same.float().mean()       # boundary points (d ~ r^2) may fall either side of a rounding
+    ar = torch.arange(B)[:, None, None]
+    ref_rows = torch.cat([xyz.cpu()[ar, want] - centers.cpu()[:, :, None, :], feats.cpu()[ar, want]], -1)
+    rows = out.cpu().view(B, G, S, 12)
+    assert torch.equal(rows[same][..., :9], ref_rows[same]) and bool((rows[..., 9:] == 0).all())
+    # groups with fewer than S hits are padded with the first hit (pointnet_util.py:106-108)
+    assert bool((want[..., -1] == want[..., 0]).any())
+
+
+@pytest.mark.parametrize('precision', ['f32', 'split'])
+def test_openshape_encoder_vs_oracle_and_reference_parts(precision):
+    """PPAT forward (SA -> lift -> LN -> blocks -> proj) vs the oracle, whose SA layer and transformer blocks are
+    pinned to the reference's own classes by g9; 2 blocks at the real widths (dim 512, 8 heads, mlp 1536)."""
+    from uni_adapter_amd.point_encoder import create_openshape_from_state_dict
+    g = _golden('g9_ppat.npz')
+    sd = O.make_ppat_state_dict(int(g['weights_seed']), depth=2)
+    xyz, feats = torch.from_numpy(g['xyz']), torch.from_numpy(g['feats'])
+    model = create_openshape_from_state_dict(sd, patches=128, nsample=64, radius=0.2, num_heads=8, precision=precision, fps_start=1)
+    out, tokens = model.point_encoder(xyz.cuda(), feats.cuda(), return_tokens=True)
+    ref, cen, sa, tok, y = O.ppat_encode(xyz, feats, sd, 128, 0.2, 64, 8, center_idx=torch.from_numpy(g['center_idx']), return_parts=True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    truth = O.ppat_encode(xyz.double(), feats.double(), sd64, 128, 0.2, 64, 8, center_idx=torch.from_numpy(g['center_idx']))
+    base = (ref.double() - truth).abs().max().item()
+    err = (out.cpu().double() - truth).abs().max().item()
+    scale = truth.abs().max().item()
+    assert err <= max(5 * base, 5e-5 * scale), (err, base, scale)
+    # token rows after the blocks against the reference Transformer's output (it was fed the oracle's token input)
+    assert (tokens.cpu() - torch.from_numpy(g['tokens_out'])).abs().max().item() <= 2e-4 * float(np.abs(g['tokens_out']).max())
+
+
+def test_openshape_full_depth_logits_wrapper():
+    """'scaling 4' shape (384 patches, 12 blocks, out 1280) through get_logits_wrapper(vlm3d='openshape')."""
+    import types
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_openshape_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import get_logits_wrapper
+    sd = synthetic.openshape_state_dict(6, depth=12)
+    pc = _clouds(2, 1024, 13)
+    model = create_openshape_from_state_dict(sd, precision='split')
+    out = model(pc[:, :, :3].contiguous().cuda(), pc.cuda())
+    ref = O.ppat_encode(pc[:, :, :3].contiguous(), pc, sd, 384, 0.2, 64, 8)
+    cos = torch.nn.functional.cosine_similarity(out.cpu().double(), ref.double(), dim=1)
+    assert (1 - cos).max().item() < 1e-8
+    assert (out.cpu() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    text = synthetic.text_bank(15, 1280, seed=2)
+    fh, z, ent, p, pred = get_logits_wrapper(types.SimpleNamespace(vlm3d='openshape'), model, pc[:1].cuda(), text.t().contiguous().cuda())
+    rz = 100.0 * torch.nn.functional.normalize(ref[:1], dim=1) @ text.t()
+    assert (z.cpu() - rz).abs().max().item() < 1e-3 and pred == int(rz.argmax())

@@ -187,3 +187,18 @@ def test_g8_ulip_pointbert_encoder(golden_dir):
     out, cat = O.ulip_encode_pc(xyz, sd, 128, 32, 6, center_idx=cidx, return_concat=True)
     assert np.abs(cat.numpy() - g['concat']).max() < 2e-5
     assert np.abs(out.numpy() - g['embed']).max() < 2e-5
+
+
+def test_g9_openshape_ppat_parts(golden_dir):
+    """Oracle restatement of the OpenShape PPAT set-abstraction layer (ball query, SA MLP + BN + max) and of
+    its transformer blocks vs the outputs of the reference's own classes (run without torch_redstone)."""
+    g = _load(golden_dir, 'g9_ppat.npz')
+    sd = O.make_ppat_state_dict(int(g['weights_seed']), depth=2)
+    xyz, feats = torch.from_numpy(g['xyz']), torch.from_numpy(g['feats'])
+    cidx = torch.from_numpy(g['center_idx'])
+    cen, sa, idx = O.ppat_set_abstraction(xyz, feats, sd, cidx, 0.2, 64)
+    assert np.array_equal(idx.numpy(), g['ball_idx'])
+    assert np.array_equal(cen.numpy(), g['sa_centers'])
+    assert np.abs(sa.numpy() - g['sa_features']).max() < 2e-6
+    y = O.ppat_transformer(torch.from_numpy(g['tokens_in']), sd, 8)
+    assert np.abs(y.numpy() - g['tokens_out']).max() < 2e-5

@@ -41,15 +41,17 @@ def softmax_entropy(x, enable_softmax=True, temperature=1.0):
 
 
 def get_logits_wrapper(args, model, feature, clip_weights):
-    """Uni_Adapter.py:53-75 for vlm3d in {'uni3d', 'ulip'}, batch 1.  `clip_weights` is (D,K) as in
+    """Uni_Adapter.py:53-75 for vlm3d in {'uni3d', 'ulip', 'openshape'}, batch 1.  `clip_weights` is (D,K) as in
     the reference.  Returns (pc_features, logits, loss, prob_map, pred:int)."""
     vlm = getattr(args, 'vlm3d', 'uni3d')
     if vlm == 'uni3d':
         feat = model.encode_pc(feature)                       # :54-57
     elif vlm == 'ulip':
         feat = model(feature[:, :, :3].contiguous())          # :58-62 (xyz only)
+    elif vlm == 'openshape':
+        feat = model(feature[:, :, :3].contiguous(), feature)   # :63-66 (xyz, and xyz+rgb as point features)
     else:
-        raise NotImplementedError("--vlm3d openshape is not built (SURVEY section 8 row F1)")
+        raise NotImplementedError(f"--vlm3d {vlm}")
     if feat.shape[0] != 1:
         raise ValueError('batch size must be 1 (reference defect 6)')
     text = clip_weights.t().contiguous()

@@ -176,6 +176,64 @@ knn_group_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb, c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Ball query + gather (OpenShape PPAT set abstraction: models/openshape/pointnet_util.py:89-146):
+// the first S points IN INDEX ORDER with squared distance <= r^2 to the centre (square_distance's
+// expanded form, :20-42), padded with the first hit; row = [p - centre (3) | point features (F)].
+// One wavefront per centre, grid (ceil(G/4), B), block 256; the cloud (xyz and |p|^2) sits in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ball_group_kernel(const float* __restrict__ xyz, const float* __restrict__ pf, const float* __restrict__ centers,
+                  int N, int G, int S, int F, float r2, float* __restrict__ feat, int ldf, int* __restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // xyz N*3 | |p|^2 N
+    float* s_xyz = smem;
+    float* s_pn = smem + 3 * N;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* p = xyz + (size_t)b * N * 3;
+    for (int i = threadIdx.x; i < N * 3; i += 256) s_xyz[i] = p[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float x = s_xyz[3 * i], y = s_xyz[3 * i + 1], z = s_xyz[3 * i + 2];
+        s_pn[i] = (x * x + y * y) + z * z;
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 4 + w;
+    if (g >= G) return;
+    const float* c = centers + ((size_t)b * G + g) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    const float cn = (cx * cx + cy * cy) + cz * cz;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const size_t grp = ((size_t)b * G + g) * S;
+    int found = 0, first = -1;
+    auto emit = [&](int pos, int i) {                                    // one lane writes row `pos` from point i
+        float* o = feat + (grp + pos) * (size_t)ldf;
+        o[0] = s_xyz[3 * i] - cx; o[1] = s_xyz[3 * i + 1] - cy; o[2] = s_xyz[3 * i + 2] - cz;        // :129
+        const float* q = pf + ((size_t)b * N + i) * F;
+        for (int t = 0; t < F; ++t) o[3 + t] = q[t];                                                  // :133-134
+        for (int t = 3 + F; t < ldf; ++t) o[t] = 0.f;
+        if (idx_out) idx_out[grp + pos] = i;
+    };
+    for (int i0 = 0; i0 < N && found < S; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < N) {
+            const float dot = fmaf(cz, s_xyz[3 * i + 2], fmaf(cy, s_xyz[3 * i + 1], cx * s_xyz[3 * i]));
+            float d = -2.f * dot;                                        // :39
+            d += cn;                                                     // :40 (src = query centre)
+            d += s_pn[i];                                                // :41
+            in = !(d > r2);                                              // group_idx[sqrdists > radius**2] = N  (:104)
+        }
+        const unsigned long long m = __ballot(in);
+        if (first < 0 && m) first = i0 + __builtin_ctzll(m);
+        const int pos = found + __popcll(m & lt_mask);
+        if (in && pos < S) emit(pos, i);
+        found += __popcll(m);
+    }
+    found = min(found, S);
+    if (first < 0) first = 0;                                            // cannot happen for a centre taken from the cloud
+    for (int pos = found + lane; pos < S; pos += 64) emit(pos, first);   // :106-108 pad with the first hit
+}
+
 }  // namespace
 
 extern "C" int ua_fps(const float* xyz, int32_t B, int32_t N, int32_t G, int32_t start, float skip_eps,
@@ -209,6 +267,22 @@ extern "C" int ua_knn_group(const float* xyz, const float* rgb, const float* cen
     if (N <= 1024)      hipLaunchKernelGGL(knn_group_kernel<16>, grid, dim3(256), lds, st, xyz, rgb, centers, N, G, S, feat, ldf, idx);
     else if (N <= 2048) hipLaunchKernelGGL(knn_group_kernel<32>, grid, dim3(256), lds, st, xyz, rgb, centers, N, G, S, feat, ldf, idx);
     else                hipLaunchKernelGGL(knn_group_kernel<64>, grid, dim3(256), lds, st, xyz, rgb, centers, N, G, S, feat, ldf, idx);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_ball_group(const float* xyz, const float* point_feat, const float* centers,
+                             int32_t B, int32_t N, int32_t G, int32_t S, int32_t F, float radius,
+                             float* feat, int32_t ldf, int32_t* idx, void* stream) {
+    UA_CHECK_PTR(xyz); UA_CHECK_PTR(point_feat); UA_CHECK_PTR(centers); UA_CHECK_PTR(feat);
+    if (B <= 0 || N <= 0 || G <= 0 || S <= 0 || F < 0 || !(radius > 0.f) || ldf < 3 + F) return UA_EINVAL;
+    if (N > 8192) return UA_EUNSUPPORTED;
+    const size_t lds = (size_t)N * 4 * sizeof(float);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ball_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return UA_ELAUNCH;
+    hipLaunchKernelGGL(ball_group_kernel, dim3((G + 3) / 4, B), dim3(256), lds, ua::as_stream(stream),
+                       xyz, point_feat, centers, N, G, S, F, radius * radius, feat, ldf, idx);
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     'ua_align_step': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _d, _d, _d, _d, _p, _p, _p, _p, _p],
     'ua_fps': [_p, _i32, _i32, _i32, _i32, _f, _p, _p, _p],
     'ua_knn_group': [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _p],
+    'ua_ball_group': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, _p, _i32, _p, _p],
     'ua_gemm': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
     'ua_layernorm': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _p],
     'ua_layernorm_split': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _f, _p],

@@ -22,10 +22,11 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser('Uni-Adapter test-time adaptation (MI355X path)')
     p.add_argument('--name', type=str, default=None)
     p.add_argument('--output-dir', type=str, default='./outputs')
-    p.add_argument('--vlm3d', type=str, default='uni3d', choices=['uni3d', 'ulip'])
+    p.add_argument('--vlm3d', type=str, default='uni3d', choices=['uni3d', 'ulip', 'openshape'])
     p.add_argument('--precomputed-text-features', type=str, default=None)
     p.add_argument('--pretrained-pc-uni3d', type=str, default=None)
     p.add_argument('--pretrained-pc-ulip', type=str, default=None)
+    p.add_argument('--pretrained-pc-oshape', type=str, default=None)
     p.add_argument('--num-group-uni3d', type=int, default=512)
     p.add_argument('--group_size_uni3d', type=int, default=64)
     p.add_argument('--myroot', type=str, required=True)

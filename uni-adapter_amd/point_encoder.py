@@ -122,7 +122,7 @@ class PointcloudEncoder(nn.Module):
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_group: int, group_size: int, num_heads: int,
                  device=None, prefix: str = 'point_encoder.', ln_eps: float = 1e-6, bn_eps: float = 1e-5,
                  fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8, precision: str = 'f32',
-                 variant: str = 'uni3d', projection: Optional[torch.Tensor] = None):
+                 variant: str = 'uni3d', projection: Optional[torch.Tensor] = None, ball_radius: float = 0.2):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('uni_adapter_amd.PointcloudEncoder needs a HIP device (MI355X); no CPU path')
@@ -136,8 +136,8 @@ class PointcloudEncoder(nn.Module):
         sp = precision == 'split'
         if self.group_size not in (32, 64):
             raise NotImplementedError('patch-embed max-pool epilogue is built for group sizes 64 (Uni3D) and 32 (PointBERT)')
-        if variant not in ('uni3d', 'ulip'):
-            raise ValueError("variant must be 'uni3d' or 'ulip'")
+        if variant not in ('uni3d', 'ulip', 'openshape'):
+            raise ValueError("variant must be 'uni3d', 'ulip' or 'openshape'")
         self.variant = variant
         sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
         if variant == 'ulip':
@@ -149,6 +149,21 @@ class PointcloudEncoder(nn.Module):
                     k2 = 'ulip_' + k2
                 ren[k2] = v
             sd = ren
+        if variant == 'openshape':
+            # OpenShape PPAT layout (models/openshape/ppta.py:83-147) -> the internal block key names; the
+            # PreNorm/Attention/FeedForward layer is a pre-LN ViT block with bias-free fused qkv and a GELU MLP
+            ren = {}
+            for k, v in sd.items():
+                k2 = k
+                if k.startswith('ppat.transformer.layers.'):
+                    l, j, rest = k[len('ppat.transformer.layers.'):].split('.', 2)
+                    rest = {'norm.weight': f'norm{int(j) + 1}.weight', 'norm.bias': f'norm{int(j) + 1}.bias',
+                            'fn.to_qkv.weight': 'attn.qkv.weight', 'fn.to_out.0.weight': 'attn.proj.weight',
+                            'fn.to_out.0.bias': 'attn.proj.bias', 'fn.net.0.weight': 'mlp.fc1.weight', 'fn.net.0.bias': 'mlp.fc1.bias',
+                            'fn.net.3.weight': 'mlp.fc2.weight', 'fn.net.3.bias': 'mlp.fc2.bias'}[rest]
+                    k2 = f'visual.blocks.{l}.{rest}'
+                ren[k2] = v
+            sd = ren
         d = lambda t: t.detach().to(self.dev, torch.float32).contiguous()
 
         def bn_affine(name):                       # eval BatchNorm1d -> per-channel scale/shift
@@ -157,39 +172,64 @@ class PointcloudEncoder(nn.Module):
             s = w / torch.sqrt(rv + bn_eps)
             return d(s), d(b - rm * s)
 
-        # ---- mini-PointNet (models/point_encoder.py:133-144) ----
-        w1 = sd['encoder.first_conv.0.weight'][:, :, 0]
-        self.in_ch = w1.shape[1]
-        self.w1 = d(torch.nn.functional.pad(w1.float(), (0, 8 - self.in_ch)))             # K padded 6 -> 8
-        self.b1 = d(sd['encoder.first_conv.0.bias'])
-        self.bn1_s, self.bn1_t = bn_affine('encoder.first_conv.1')
-        self.w2 = d(sd['encoder.first_conv.3.weight'][:, :, 0]); self.b2 = d(sd['encoder.first_conv.3.bias'])
-        self.c_loc = self.w2.shape[0]                                             # 256
-        w3 = sd['encoder.second_conv.0.weight'][:, :, 0]
-        self.w3g = d(w3[:, :self.c_loc]); self.w3l = d(w3[:, self.c_loc:])        # [global | local] halves
-        self.b3 = d(sd['encoder.second_conv.0.bias'])
-        self.bn2_s, self.bn2_t = bn_affine('encoder.second_conv.1')
-        self.w4 = d(sd['encoder.second_conv.3.weight'][:, :, 0]); self.b4 = d(sd['encoder.second_conv.3.bias'])
-        self.enc_dim = self.w4.shape[0]
-        self.n3 = self.w3l.shape[0]
-        if sp:                                    # the three big convs go through the split kernel
-            self.w2, self.w3l, self.w4 = SplitW(self.w2), SplitW(self.w3l), SplitW(self.w4)
-        # ---- bridges / positional MLP (:175-186) ----
-        self.w_e2t = d(sd['encoder2trans.weight']); self.b_e2t = d(sd['encoder2trans.bias'])
-        self.trans_dim = self.w_e2t.shape[0]
-        if variant == 'uni3d':
-            self.w_t2e = d(sd['trans2embed.weight']); self.b_t2e = d(sd['trans2embed.bias'])
+        if variant == 'openshape':
+            # ---- set abstraction MLP (pointnet_util.py:169-211) + lift (ppta.py:94) + head (ppta.py:139-147) ----
+            self.ball_radius = float(ball_radius)
+            self.sa = []
+            i = 0
+            while f'ppat.sa.mlp_convs.{i}.weight' in sd:
+                wc = sd[f'ppat.sa.mlp_convs.{i}.weight'].reshape(sd[f'ppat.sa.mlp_convs.{i}.weight'].shape[0], -1).float()
+                kin = wc.shape[1]
+                wc = torch.nn.functional.pad(wc, (0, _round_up(kin, 4) - kin))
+                sc, sh = bn_affine(f'ppat.sa.mlp_bns.{i}')
+                self.sa.append((d(wc), d(sd[f'ppat.sa.mlp_convs.{i}.bias']), sc, sh))
+                i += 1
+            self.in_ch = sd['ppat.sa.mlp_convs.0.weight'].shape[1]                 # 3 + F
+            self.sa_dim = self.sa[-1][0].shape[0]
+            wl = sd['ppat.lift.0.weight'][:, :, 0].float()                          # (dim, 3 + sa_dim) on cat[centroids, feature]
+            self.lift_k = _round_up(self.sa_dim + 3, 4)
+            wl = torch.cat([wl[:, 3:], wl[:, :3]], 1)                               # our row layout: [feature | centroid]
+            self.w_lift = d(torch.nn.functional.pad(wl, (0, self.lift_k - wl.shape[1]))); self.b_lift = d(sd['ppat.lift.0.bias'])
+            self.lift_ln = (d(sd['ppat.lift.2.weight']), d(sd['ppat.lift.2.bias']))
+            self.cls_token = d(sd['ppat.cls_token'].reshape(-1))
+            self.trans_dim = self.w_lift.shape[0]
+            self.w_t2e = d(sd['proj.weight']); self.b_t2e = d(sd['proj.bias'])
             self.embed_dim = self.w_t2e.shape[0]
+            self.enc_dim = self.sa_dim
         else:
-            # ULIP: pc_embed = cat[cls, max(tokens)] @ pc_projection (models/ulip/ulip_model.py:15-18)
-            if projection is None:
-                raise ValueError("variant 'ulip' needs the pc_projection matrix (2*trans_dim, embed)")
-            self.w_t2e = d(projection.t()); self.b_t2e = None
-            self.embed_dim = self.w_t2e.shape[0]
-            self.ulip_norm = (d(sd['ulip_norm.weight']), d(sd['ulip_norm.bias']))
-        self.w_p0 = d(torch.nn.functional.pad(sd['pos_embed.0.weight'], (0, 1))); self.b_p0 = d(sd['pos_embed.0.bias'])
-        self.w_p2 = d(sd['pos_embed.2.weight']); self.b_p2 = d(sd['pos_embed.2.bias'])
-        self.cls_token = d(sd['cls_token'].reshape(-1)); self.cls_pos = d(sd['cls_pos'].reshape(-1))
+            # ---- mini-PointNet (models/point_encoder.py:133-144) ----
+            w1 = sd['encoder.first_conv.0.weight'][:, :, 0]
+            self.in_ch = w1.shape[1]
+            self.w1 = d(torch.nn.functional.pad(w1.float(), (0, 8 - self.in_ch)))             # K padded 6 -> 8
+            self.b1 = d(sd['encoder.first_conv.0.bias'])
+            self.bn1_s, self.bn1_t = bn_affine('encoder.first_conv.1')
+            self.w2 = d(sd['encoder.first_conv.3.weight'][:, :, 0]); self.b2 = d(sd['encoder.first_conv.3.bias'])
+            self.c_loc = self.w2.shape[0]                                             # 256
+            w3 = sd['encoder.second_conv.0.weight'][:, :, 0]
+            self.w3g = d(w3[:, :self.c_loc]); self.w3l = d(w3[:, self.c_loc:])        # [global | local] halves
+            self.b3 = d(sd['encoder.second_conv.0.bias'])
+            self.bn2_s, self.bn2_t = bn_affine('encoder.second_conv.1')
+            self.w4 = d(sd['encoder.second_conv.3.weight'][:, :, 0]); self.b4 = d(sd['encoder.second_conv.3.bias'])
+            self.enc_dim = self.w4.shape[0]
+            self.n3 = self.w3l.shape[0]
+            if sp:                                    # the three big convs go through the split kernel
+                self.w2, self.w3l, self.w4 = SplitW(self.w2), SplitW(self.w3l), SplitW(self.w4)
+            # ---- bridges / positional MLP (:175-186) ----
+            self.w_e2t = d(sd['encoder2trans.weight']); self.b_e2t = d(sd['encoder2trans.bias'])
+            self.trans_dim = self.w_e2t.shape[0]
+            if variant == 'uni3d':
+                self.w_t2e = d(sd['trans2embed.weight']); self.b_t2e = d(sd['trans2embed.bias'])
+                self.embed_dim = self.w_t2e.shape[0]
+            else:
+                # ULIP: pc_embed = cat[cls, max(tokens)] @ pc_projection (models/ulip/ulip_model.py:15-18)
+                if projection is None:
+                    raise ValueError("variant 'ulip' needs the pc_projection matrix (2*trans_dim, embed)")
+                self.w_t2e = d(projection.t()); self.b_t2e = None
+                self.embed_dim = self.w_t2e.shape[0]
+                self.ulip_norm = (d(sd['ulip_norm.weight']), d(sd['ulip_norm.bias']))
+            self.w_p0 = d(torch.nn.functional.pad(sd['pos_embed.0.weight'], (0, 1))); self.b_p0 = d(sd['pos_embed.0.bias'])
+            self.w_p2 = d(sd['pos_embed.2.weight']); self.b_p2 = d(sd['pos_embed.2.bias'])
+            self.cls_token = d(sd['cls_token'].reshape(-1)); self.cls_pos = d(sd['cls_pos'].reshape(-1))
         Cd = self.trans_dim
         if Cd % self.num_heads or Cd // self.num_heads != 64:
             raise NotImplementedError('attention kernel is built for head_dim 64')
@@ -257,6 +297,15 @@ class PointcloudEncoder(nn.Module):
         rows = Bc * G + Bc
         Hp = max(b.Hp for b in self.blocks) if self.blocks else 32
         e = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
+        if self.variant == 'openshape':
+            kin = self.sa[0][0].shape[1]
+            ws = dict(centers=e(Bc, G, 3), feat=e(Mp, kin), liftin=torch.zeros(Bc * G, self.lift_k, device=self.dev),
+                      tokc=e(Bc * G, Cd), x=e(rows, Cd), h=e(rows, Cd), qkv=e(rows, 3 * Cd), att=e(rows, Cd),
+                      hid=e(rows, Hp), hidn=e(rows, Hp))
+            for i, (wc, _, _, _) in enumerate(self.sa[:-1]):
+                ws[f'sa{i}'] = e(Mp, wc.shape[0])
+            self._ws[Bc] = ws
+            return ws
         ws = dict(
             centers=e(Bc, G, 3), centers4=torch.zeros(Bc * G, 4, device=self.dev), feat=e(Mp, 8),
             h1=e(Mp, 128), loc=e(Mp, self.c_loc), glob=e(pc * G, self.c_loc), g3=e(pc * G, self.n3),
@@ -266,60 +315,13 @@ class PointcloudEncoder(nn.Module):
         self._ws[Bc] = ws
         return ws
 
-    # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, pts, colors=None, return_tokens=False):
-        """pts, colors: (Bc,N,3) fp32 on device -> (Bc, embed_dim)  (models/point_encoder.py:192-223;
-        variant 'ulip': xyz only, models/ulip/pointbert/point_encoder.py:173-192)."""
-        Bc, N, _ = pts.shape
+    def _run_blocks(self, w, Bc):
+        """The transformer blocks on the token rows of w['x'] (in place); returns w['x']."""
         G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
-        pts = pts.to(self.dev, torch.float32).contiguous()
-        if self.variant == 'uni3d':
-            colors = colors.to(self.dev, torch.float32).contiguous()
-        else:
-            colors = None
-        w = self._workspace(Bc)
-        st = lib.stream_ptr()
-        # ---- grouping (:108-127) ----
-        lib.call('ua_fps', pts.data_ptr(), Bc, N, G, self.fps_start, self.fps_skip_eps, None, w['centers'].data_ptr(), st)
-        w['centers4'][:, :3].copy_(w['centers'].view(-1, 3))
-        # ---- mini-PointNet per chunk of clouds (:145-159) ----
         sp = self.precision == 'split'
-        pc = min(self.pe_clouds, Bc)
-        for c0 in range(0, Bc, pc):
-            nb = min(pc, Bc - c0)
-            Mp, Mg = nb * G * S, nb * G
-            lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr() if colors is not None else None, w['centers'][c0:].data_ptr(),
-                     nb, N, G, S, w['feat'].data_ptr(), 8, None, st)
-            n3 = self.n3
-            if not sp:
-                _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
-                      alg_flops=2.0 * Mp * 128 * self.in_ch)
-                _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
-                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S)
-                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
-                _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
-                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
-                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
-                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
-            else:
-                # same chain; the per-point activations h1 / loc / h3 only ever exist in split form
-                _gemm(w['feat'], 8, self.w1, None, 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
-                      alg_flops=2.0 * Mp * 128 * self.in_ch, split_out=w['h1'], ld_split=128)
-                _gemm(w['h1'], 128, self.w2, None, self.c_loc, Mp, self.c_loc, 128, bias=self.b2, a_scale=1.0,
-                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S, split_out=w['loc'], ld_split=self.c_loc)
-                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
-                _gemm(w['loc'], self.c_loc, self.w3l, None, n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
-                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU, a_scale=1.0, split_out=w['h3'], ld_split=n3)
-                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4, a_scale=1.0,
-                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
-        # ---- token assembly (:198-208) ----
+        st = lib.stream_ptr()
         Mg = Bc * G
-        _gemm(w['tok'], self.enc_dim, self.w_e2t, w['tokc'], Cd, Mg, Cd, self.enc_dim, bias=self.b_e2t)
-        _gemm(w['centers4'], 4, self.w_p0, w['posh'], 128, Mg, 128, 4, bias=self.b_p0, act=ACT_GELU, alg_flops=2.0 * Mg * 128 * 3)
-        _gemm(w['posh'], 128, self.w_p2, w['pos'], Cd, Mg, Cd, 128, bias=self.b_p2)
-        lib.call('ua_assemble_tokens', w['tokc'].data_ptr(), w['pos'].data_ptr(), self.cls_token.data_ptr(),
-                 self.cls_pos.data_ptr(), w['x'].data_ptr(), Bc, G, Cd, st)
         # ---- transformer blocks (:217-218) ----
         rows = Mg + Bc
         x = w['x']
@@ -371,6 +373,106 @@ class PointcloudEncoder(nn.Module):
                 lib.call('ua_split_f16', hid.data_ptr(), ld_h, w['hidn'].data_ptr(), ld_h, rows, b.H, Hp, 1.0, st)
                 hid, s_h = w['hidn'], 1.0
             _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H, a_scale=s_h)
+        return x
+
+    @torch.no_grad()
+    def _forward_openshape(self, pts, feats, w, Bc, N, return_tokens):
+        """OpenShape PPAT (models/openshape/ppta.py:113-147): ball-query set abstraction -> lift + LayerNorm ->
+        [tokens, cls] -> pre-LN blocks -> Linear on the CLS token."""
+        G, S, Cd = self.num_group, self.group_size, self.trans_dim
+        st = lib.stream_ptr()
+        F_ = feats.shape[2]
+        if 3 + F_ != self.in_ch:
+            raise ValueError(f'point features have {F_} channels, the SA layer expects {self.in_ch - 3}')
+        kin = self.sa[0][0].shape[1]
+        pc = min(self.pe_clouds, Bc)
+        for c0 in range(0, Bc, pc):
+            nb = min(pc, Bc - c0)
+            Mp = nb * G * S
+            lib.call('ua_ball_group', pts[c0:].data_ptr(), feats[c0:].data_ptr(), w['centers'][c0:].data_ptr(), nb, N, G, S, F_,
+                     self.ball_radius, w['feat'].data_ptr(), kin, None, st)
+            cur, ldcur, kcur = w['feat'], kin, kin
+            for i, (wc, bc, sc, sh) in enumerate(self.sa):                    # conv1x1 + BN + ReLU (pointnet_util.py:203-205)
+                co = wc.shape[0]
+                if i + 1 < len(self.sa):
+                    _gemm(cur, ldcur, wc, w[f'sa{i}'], co, Mp, co, kcur, bias=bc, scale=sc, shift=sh, act=ACT_RELU)
+                    cur, ldcur, kcur = w[f'sa{i}'], co, co
+                else:                                                          # last layer: only the max over the group is kept (:207)
+                    _gemm(cur, ldcur, wc, None, co, Mp, co, kcur, bias=bc, scale=sc, shift=sh, act=ACT_RELU,
+                          pool_out=w['liftin'][c0 * G:], ldp=self.lift_k, pool_rows=S)
+        Mg = Bc * G
+        w['liftin'][:, self.sa_dim:self.sa_dim + 3].copy_(w['centers'].view(-1, 3))          # rows = [feature | centroid]
+        _gemm(w['liftin'], self.lift_k, self.w_lift, w['tokc'], Cd, Mg, Cd, self.lift_k, bias=self.b_lift,
+              alg_flops=2.0 * Mg * Cd * (self.sa_dim + 3))
+        x = w['x']
+        _ln(w['tokc'], Cd, self.lift_ln[0], self.lift_ln[1], 1e-5, x, Cd, Mg, Cd, Cd)        # nn.LayerNorm([dim]) of the lift
+        x[Mg:].copy_(self.cls_token.expand(Bc, Cd))                                           # cls token rows (no positional term)
+        self._run_blocks(w, Bc)
+        out = torch.empty(Bc, self.embed_dim, device=self.dev, dtype=torch.float32)
+        _gemm(x[Mg:], Cd, self.w_t2e, out, self.embed_dim, Bc, self.embed_dim, Cd, bias=self.b_t2e)      # proj(cls) (:141-142)
+        if return_tokens:
+            return out, torch.cat([x[Mg:].view(Bc, 1, Cd), x[:Mg].view(Bc, G, Cd)], 1)
+        return out
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, pts, colors=None, return_tokens=False):
+        """pts, colors: (Bc,N,3) fp32 on device -> (Bc, embed_dim)  (models/point_encoder.py:192-223;
+        variant 'ulip': xyz only, models/ulip/pointbert/point_encoder.py:173-192)."""
+        Bc, N, _ = pts.shape
+        G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
+        pts = pts.to(self.dev, torch.float32).contiguous()
+        if self.variant in ('uni3d', 'openshape'):
+            colors = colors.to(self.dev, torch.float32).contiguous()        # openshape: the (Bc,N,F) point features
+        else:
+            colors = None
+        w = self._workspace(Bc)
+        st = lib.stream_ptr()
+        # ---- grouping (:108-127) ----
+        lib.call('ua_fps', pts.data_ptr(), Bc, N, G, self.fps_start, self.fps_skip_eps, None, w['centers'].data_ptr(), st)
+        if self.variant == 'openshape':
+            return self._forward_openshape(pts, colors, w, Bc, N, return_tokens)
+        w['centers4'][:, :3].copy_(w['centers'].view(-1, 3))
+        # ---- mini-PointNet per chunk of clouds (:145-159) ----
+        sp = self.precision == 'split'
+        pc = min(self.pe_clouds, Bc)
+        for c0 in range(0, Bc, pc):
+            nb = min(pc, Bc - c0)
+            Mp, Mg = nb * G * S, nb * G
+            lib.call('ua_knn_group', pts[c0:].data_ptr(), colors[c0:].data_ptr() if colors is not None else None, w['centers'][c0:].data_ptr(),
+                     nb, N, G, S, w['feat'].data_ptr(), 8, None, st)
+            n3 = self.n3
+            if not sp:
+                _gemm(w['feat'], 8, self.w1, w['h1'], 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
+                      alg_flops=2.0 * Mp * 128 * self.in_ch)
+                _gemm(w['h1'], 128, self.w2, w['loc'], self.c_loc, Mp, self.c_loc, 128, bias=self.b2,
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S)
+                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
+                _gemm(w['loc'], self.c_loc, self.w3l, w['h3'], n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
+                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU)
+                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4,
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
+            else:
+                # same chain; the per-point activations h1 / loc / h3 only ever exist in split form
+                _gemm(w['feat'], 8, self.w1, None, 128, Mp, 128, 8, bias=self.b1, scale=self.bn1_s, shift=self.bn1_t, act=ACT_RELU,
+                      alg_flops=2.0 * Mp * 128 * self.in_ch, split_out=w['h1'], ld_split=128)
+                _gemm(w['h1'], 128, self.w2, None, self.c_loc, Mp, self.c_loc, 128, bias=self.b2, a_scale=1.0,
+                      pool_out=w['glob'], ldp=self.c_loc, pool_rows=S, split_out=w['loc'], ld_split=self.c_loc)
+                _gemm(w['glob'], self.c_loc, self.w3g, w['g3'], n3, Mg, n3, self.c_loc)
+                _gemm(w['loc'], self.c_loc, self.w3l, None, n3, Mp, n3, self.c_loc, bias=self.b3, rowgroup_add=w['g3'], ldg=n3,
+                      group_rows=S, scale=self.bn2_s, shift=self.bn2_t, act=ACT_RELU, a_scale=1.0, split_out=w['h3'], ld_split=n3)
+                _gemm(w['h3'], n3, self.w4, None, self.enc_dim, Mp, self.enc_dim, n3, bias=self.b4, a_scale=1.0,
+                      pool_out=w['tok'][c0 * G:], ldp=self.enc_dim, pool_rows=S)
+        # ---- token assembly (:198-208) ----
+        Mg = Bc * G
+        _gemm(w['tok'], self.enc_dim, self.w_e2t, w['tokc'], Cd, Mg, Cd, self.enc_dim, bias=self.b_e2t)
+        _gemm(w['centers4'], 4, self.w_p0, w['posh'], 128, Mg, 128, 4, bias=self.b_p0, act=ACT_GELU, alg_flops=2.0 * Mg * 128 * 3)
+        _gemm(w['posh'], 128, self.w_p2, w['pos'], Cd, Mg, Cd, 128, bias=self.b_p2)
+        lib.call('ua_assemble_tokens', w['tokc'].data_ptr(), w['pos'].data_ptr(), self.cls_token.data_ptr(),
+                 self.cls_pos.data_ptr(), w['x'].data_ptr(), Bc, G, Cd, st)
+        x = self._run_blocks(w, Bc)
+        Mg = Bc * G
+        rows = Mg + Bc
         out = torch.empty(Bc, self.embed_dim, device=self.dev, dtype=torch.float32)
         if self.variant == 'uni3d':
             # ---- head (:219-222) on the CLS rows ----
@@ -397,8 +499,12 @@ class PointcloudEncoder(nn.Module):
         """Algorithmic FLOPs of one forward (SURVEY section 8d bookkeeping, reference formulation)."""
         G, S, Cd = self.num_group, self.group_size, self.trans_dim
         T = G + 1
-        f = G * S * 2 * (self.in_ch * 128 + 128 * self.c_loc + (2 * self.c_loc) * self.n3 + self.n3 * self.enc_dim)
-        f += G * 2 * (self.enc_dim * Cd + 3 * 128 + 128 * Cd)
+        if self.variant == 'openshape':
+            chans = [self.in_ch] + [wc.shape[0] for wc, _, _, _ in self.sa]
+            f = G * S * 2 * sum(a * b for a, b in zip(chans[:-1], chans[1:])) + G * 2 * (self.sa_dim + 3) * Cd
+        else:
+            f = G * S * 2 * (self.in_ch * 128 + 128 * self.c_loc + (2 * self.c_loc) * self.n3 + self.n3 * self.enc_dim)
+            f += G * 2 * (self.enc_dim * Cd + 3 * 128 + 128 * Cd)
         for b in self.blocks:
             f += 2 * T * Cd * Cd * 4 + 4 * T * T * Cd
             f += 2 * T * Cd * b.H * (3 if b.act == ACT_SWIGLU else 2)
@@ -455,3 +561,26 @@ def create_ulip_from_state_dict(state_dict, num_group=512, group_size=32, num_he
     kw.setdefault('fps_skip_eps', -1.0)            # pure-torch FPS of models/ulip/pointbert/misc.py:40-60
     enc = PointcloudEncoder(sd, num_group, group_size, num_heads, variant='ulip', projection=sd['pc_projection'], **kw)
     return ULIP(enc)
+
+
+class OpenShape(nn.Module):
+    """Mirror of models/openshape/ppta.py:135-142 (`Projected`): `model(xyz[B,N,3], features[B,N,F]) -> (B, out_channel)`
+    as called at Uni_Adapter.py:63-66."""
+
+    def __init__(self, point_encoder: PointcloudEncoder):
+        super().__init__()
+        self.point_encoder = point_encoder
+
+    def forward(self, xyz, features):
+        return self.point_encoder(xyz[:, :, :3].contiguous(), features.contiguous())
+
+
+def create_openshape_from_state_dict(state_dict, patches=384, nsample=64, radius=0.2, num_heads=8, **kw):
+    """OpenShape PointBERT 'scaling 4' (models/openshape/ppta.py:172-177, config.yaml) from a state dict in the key layout of
+    `Projected(PointPatchTransformer, nn.Linear)`: `ppat.sa.*`, `ppat.lift.*`, `ppat.cls_token`, `ppat.transformer.layers.*`,
+    `proj.*`.  The reference's own loader is a stub (utils/load_models.py:108-127), so this factory defines the wiring."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+    kw.setdefault('ln_eps', 1e-5)                  # nn.LayerNorm default
+    kw.setdefault('fps_skip_eps', -1.0)            # pure-torch FPS (pointnet_util.py:64-86; random start: pass fps_start)
+    enc = PointcloudEncoder(sd, patches, nsample, num_heads, variant='openshape', prefix='', ball_radius=radius, **kw)
+    return OpenShape(enc)

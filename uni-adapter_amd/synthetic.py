@@ -87,6 +87,35 @@ def ulip_state_dict(seed=0, trans_dim=384, embed_dim=512, enc_dim=256, depth=12,
     return sd
 
 
+def openshape_state_dict(seed=0, dim=512, depth=12, heads=8, mlp_dim=1536, sa_dim=256, in_dim=6, out_dim=1280, device='cpu'):
+    """Random-init weights in the key layout of OpenShape's `Projected(PointPatchTransformer, nn.Linear)`
+    (models/openshape/ppta.py:83-147; 'scaling 4' = PointBERT-ViT-G: 384 patches, radius 0.2, 64 samples)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s, scale=0.02: torch.randn(*s, generator=g, device=device) * scale
+    sd = {}
+    last = in_dim + 3
+    for i, c in enumerate([64, 64, sa_dim]):
+        sd[f'ppat.sa.mlp_convs.{i}.weight'] = rn(c, last, 1, 1, scale=1 / math.sqrt(last)); sd[f'ppat.sa.mlp_convs.{i}.bias'] = rn(c)
+        sd[f'ppat.sa.mlp_bns.{i}.weight'] = 1 + rn(c, scale=0.1); sd[f'ppat.sa.mlp_bns.{i}.bias'] = rn(c, scale=0.1)
+        sd[f'ppat.sa.mlp_bns.{i}.running_mean'] = rn(c, scale=0.1)
+        sd[f'ppat.sa.mlp_bns.{i}.running_var'] = 1 + 0.2 * torch.rand(c, generator=g, device=device)
+        last = c
+    sd['ppat.lift.0.weight'] = rn(dim, sa_dim + 3, 1, scale=1 / math.sqrt(sa_dim + 3)); sd['ppat.lift.0.bias'] = rn(dim)
+    sd['ppat.lift.2.weight'] = 1 + rn(dim, scale=0.05); sd['ppat.lift.2.bias'] = rn(dim, scale=0.05)
+    sd['ppat.cls_token'] = rn(dim, scale=1.0)
+    inner = heads * 64
+    for l in range(depth):
+        P = f'ppat.transformer.layers.{l}.'
+        for j in (0, 1):
+            sd[P + f'{j}.norm.weight'] = 1 + rn(dim, scale=0.05); sd[P + f'{j}.norm.bias'] = rn(dim, scale=0.05)
+        sd[P + '0.fn.to_qkv.weight'] = rn(3 * inner, dim, scale=1 / math.sqrt(dim))
+        sd[P + '0.fn.to_out.0.weight'] = rn(dim, inner, scale=1 / math.sqrt(inner)); sd[P + '0.fn.to_out.0.bias'] = rn(dim)
+        sd[P + '1.fn.net.0.weight'] = rn(mlp_dim, dim, scale=1 / math.sqrt(dim)); sd[P + '1.fn.net.0.bias'] = rn(mlp_dim)
+        sd[P + '1.fn.net.3.weight'] = rn(dim, mlp_dim, scale=1 / math.sqrt(mlp_dim)); sd[P + '1.fn.net.3.bias'] = rn(dim)
+    sd['proj.weight'] = rn(out_dim, dim, scale=1 / math.sqrt(dim)); sd['proj.bias'] = rn(out_dim)
+    return sd
+
+
 def point_clouds(n, n_points=1024, seed=42, device='cpu'):
     """randn clouds scaled into the unit sphere, rgb = ones (data/tta_datasets.py:127)."""
     g = torch.Generator(device=device).manual_seed(seed)

@@ -106,9 +106,10 @@ def load_text_bank(path, device='cpu'):
 def load_point_encoder(args, device='cuda'):
     """Build the MI355X encoder from a checkpoint in the reference's layout (`utils/load_models.py:53-59,64-106`):
     Uni3D: torch.save({'module': state_dict}); ULIP: {'state_dict': ...} with `module.` prefixes."""
-    from .point_encoder import create_uni3d_from_state_dict, create_ulip_from_state_dict
+    from .point_encoder import create_openshape_from_state_dict, create_ulip_from_state_dict, create_uni3d_from_state_dict
     vlm = getattr(args, 'vlm3d', 'uni3d')
-    path = getattr(args, 'pretrained_pc_uni3d' if vlm == 'uni3d' else 'pretrained_pc_ulip', None) or getattr(args, 'ckpt_path', None)
+    key = {'uni3d': 'pretrained_pc_uni3d', 'ulip': 'pretrained_pc_ulip', 'openshape': 'pretrained_pc_oshape'}.get(vlm, 'ckpt_path')
+    path = getattr(args, key, None) or getattr(args, 'ckpt_path', None)
     if not path or not os.path.exists(path):
         raise FileNotFoundError(f'{vlm} checkpoint not found: {path}')
     ck = torch.load(path, map_location='cpu', weights_only=True)
@@ -118,4 +119,6 @@ def load_point_encoder(args, device='cuda'):
         return create_uni3d_from_state_dict(sd, args, device=device, precision=precision)
     if vlm == 'ulip':
         return create_ulip_from_state_dict(sd, device=device, precision=precision)
-    raise NotImplementedError("--vlm3d openshape is not built (SURVEY section 8 row F1)")
+    if vlm == 'openshape':                 # the reference's loader is a stub (utils/load_models.py:108-127): the wiring is ours
+        return create_openshape_from_state_dict(sd, device=device, precision=precision)
+    raise NotImplementedError(f'--vlm3d {vlm}')
