@@ -1,3 +1,5 @@
+# PMC passes of the round: one counter group per rocprofv3 run (FETCH_SIZE and WRITE_SIZE cannot share a pass),
+# each under its own timeout.  Run on the GPU box:  bash tools/pmc_passes.sh ; then python tools/pmc_collect.py gpurun_out/pmc_r1f_?
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { n=$1; shift; echo "pass $n: $*" >> $R/gpurun_out/pmc_r1f_progress.log; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r1f_$n -- python3 $R/tools/pmc_probe.py > $R/gpurun_out/pmc_r1f_$n.log 2>&1; echo "pass $n rc=$?" >> $R/gpurun_out/pmc_r1f_progress.log; }

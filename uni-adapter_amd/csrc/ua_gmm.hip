@@ -385,17 +385,6 @@ struct AlignStepArgs {
     float step_size, w1, beta2, omb2, bc2_sqrt, adam_eps;
 };
 
-__device__ __forceinline__ float block_max_f(float v, float* scratch) {
-    v = ua::wave_max(v);
-    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[w] = v;
-    __syncthreads();
-    float t = scratch[0];
-    for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
-    return t;
-}
-
 // block_sum over the first `nw` waves only (all threads of the block must call it)
 __device__ __forceinline__ double block_sum_first(double v, double* scratch, int nw) {
     v = ua::wave_sum(v);
