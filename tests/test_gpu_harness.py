@@ -251,3 +251,26 @@ def test_owner_replay_mode_two_ranks_on_one_gpu(tmp_path):
     got = torch.load(out, weights_only=True)
     assert torch.equal(got['finals'], ref.cpu())
     assert got['acc'] == ref_acc and torch.load(out + '.r1', weights_only=True)['acc'] == ref_acc
+
+
+@pytest.mark.parametrize('family', ['ulip', 'openshape'])
+def test_harness_drives_the_other_encoder_families(family):
+    """test_zeroshot_3d_core with a ULIP-2 / OpenShape model: TtaEngine only needs `encode_pc(B,N,6)`."""
+    import types
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_ulip_from_state_dict, create_openshape_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import test_zeroshot_3d_core as core
+    if family == 'ulip':
+        model = create_ulip_from_state_dict(synthetic.ulip_state_dict(2, depth=1, embed_dim=256, device='cuda'), num_group=128, device='cuda')
+        D = 256
+    else:
+        model = create_openshape_from_state_dict(synthetic.openshape_state_dict(2, depth=1, out_dim=256, device='cuda'), patches=128, device='cuda')
+        D = 256
+    K, n = 7, 6
+    xyz, rgb = synthetic.point_clouds(n, 1024, seed=5)
+    loader = [(xyz[i:i + 2], torch.arange(i, i + 2) % K, ['x'] * 2, rgb[i:i + 2]) for i in range(0, n, 2)]
+    args = types.SimpleNamespace(use_mode_dota=True, dota_epsilon=1e-4, dota_sigma=1e-4, dota_eta=0.1, dota_rho=0.02, mode_M=2, device='cuda',
+                                 precomputed_text_features=synthetic.text_bank(K, D, seed=1), res_learning=True, chunk_size=4, vlm3d=family,
+                                 aug_noise=lambda i, pc: torch.zeros_like(pc))
+    acc = core(loader, 'x', model, None, None, args, None)
+    assert set(acc) == {'acc1', 'acc3', 'acc5'} and 0.0 <= acc['acc1'] <= acc['acc5'] <= 100.0

@@ -135,6 +135,27 @@ def cache():
     print(f'residual step K=40: loglik fwd {t1 * 1e3:.1f} us, align {t2 * 1e3:.1f} us, bwd {t3 * 1e3:.1f} us')
 
 
+def encoders():
+    """Forward throughput of the three encoder families at their reference shapes (random weights, 32 clouds of 1024 points)."""
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict, create_ulip_from_state_dict, create_openshape_from_state_dict
+    Bc = 32
+    xyz, rgb = synthetic.point_clouds(Bc, 1024, seed=1, device='cuda')
+    pc = torch.cat([xyz, rgb], -1)
+    print('== encoder forwards, 32 clouds x 1024 points')
+    for prec in ('split', 'f32'):
+        models = {
+            'Uni3D-L (512x64 groups, 24 blocks x 1024)': (create_uni3d_from_state_dict(synthetic.uni3d_state_dict(0, device='cuda'), num_group=512, group_size=64, num_heads=16, device='cuda', precision=prec), lambda m: m.encode_pc(pc)),
+            'ULIP-2 PointBERT (512x32 groups, 12 blocks x 384)': (create_ulip_from_state_dict(synthetic.ulip_state_dict(0, device='cuda'), device='cuda', precision=prec), lambda m: m.encode_pc(pc)),
+            'OpenShape PPAT (384x64 balls, 12 blocks x 512)': (create_openshape_from_state_dict(synthetic.openshape_state_dict(0, device='cuda'), device='cuda', precision=prec), lambda m: m.encode_pc(pc)),
+        }
+        for name, (m, fn) in models.items():
+            med, _ = timeit(lambda: fn(m), reps=5, warm=2)
+            gf = m.point_encoder.flops_per_cloud() * Bc / 1e9
+            print(f'{prec:5s} {name:52s} {med:8.2f} ms  {Bc / med * 1e3:8.0f} clouds/s  {gf / med:7.1f} TFLOP/s (algorithmic)')
+        del models
+
+
 def replay():
     """In-order cache replay alone (ua_tta_chunk, K=40 M=8 D=1024, residual learning on): ms per sample."""
     import ctypes
@@ -158,6 +179,6 @@ def replay():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay']
+    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay', 'encoders']
     for w in which:
         globals()[w]()

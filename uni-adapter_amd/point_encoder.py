@@ -552,6 +552,10 @@ class ULIP(nn.Module):
     def forward(self, pc):
         return self.point_encoder(pc[:, :, :3].contiguous())
 
+    def encode_pc(self, pc):
+        """(B,N,6) harness batches: xyz only, as Uni_Adapter.py:58-60 slices them (lets TtaEngine drive any encoder)."""
+        return self.forward(pc)
+
 
 def create_ulip_from_state_dict(state_dict, num_group=512, group_size=32, num_heads=6, **kw):
     """ULIP-2 PointBERT (`models/ulip/pointbert/PointTransformer_8192point.yaml:15-25`) from a
@@ -573,6 +577,10 @@ class OpenShape(nn.Module):
 
     def forward(self, xyz, features):
         return self.point_encoder(xyz[:, :, :3].contiguous(), features.contiguous())
+
+    def encode_pc(self, pc):
+        """(B,N,6) harness batches: model(xyz, feature) as at Uni_Adapter.py:63-65."""
+        return self.forward(pc[:, :, :3], pc)
 
 
 def create_openshape_from_state_dict(state_dict, patches=384, nsample=64, radius=0.2, num_heads=8, **kw):
