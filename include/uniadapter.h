@@ -282,6 +282,25 @@ int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int32_t* targe
                  int64_t sample_index0, int64_t adam_step0, float* final_logits,
                  int32_t* ranks, int32_t* preds, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Full-covariance DOTA (dota.py:19-87).
+ * ua_dota_fit (:42-66): Sigma (K,D,D), mu (K,D), c (K) updated in place from x (B,D) and soft labels
+ *   y (B,K), B <= 64; also writes overall_Sigma = mean_k Sigma_k (D,D) and A = (1-eps) overall + eps I
+ *   (the matrix ua-side update() inverts, :70-71).  D % 4 == 0.
+ * ua_spd_inverse_small: out = inverse of the n x n block at A (n <= 64; principal blocks / Schur
+ *   complements of an SPD matrix): base case of the blocked inversion driven from the host with ua_gemm.
+ * ua_to_half: fp32 -> fp16 (round to nearest even), e.g. Lambda.half() (:72).
+ * ua_dota_predict (:75-86): Lambda_half (D,D) fp16, mu (K,D) fp32, X_half (B,D) fp16 ->
+ *   W_half (D,K) fp16 workspace and scores (B,K) (fp16 values stored as fp32): every tensor the
+ *   reference materialises is rounded to fp16 at the same point, sums accumulate in fp32.
+ * ------------------------------------------------------------------------------------------ */
+int ua_dota_fit(float* Sigma, float* mu, float* c, const float* x, const float* y,
+                int32_t B, int32_t K, int32_t D, float eps, float* overall_Sigma, float* A, void* stream);
+int ua_spd_inverse_small(const float* A, int64_t lda, int32_t n, float* out, int64_t ldo, void* stream);
+int ua_to_half(const float* x, void* y_half, int64_t n, void* stream);
+int ua_dota_predict(const void* Lambda_half, const float* mu, const void* X_half, int32_t B, int32_t K, int32_t D,
+                    void* W_half, float* scores, void* stream);
+
 /* PointBERT / ULIP-2 variant (models/ulip/pointbert/point_encoder.py:95-98,173-192):
  * ua_add_pos: x += pos before every block (patch rows get pos[b*G+g], CLS rows cls_pos).
  * ua_cls_max_concat: out (Bc, 2C) = [x_cls | max over the G patch tokens] (:190).                */

@@ -374,6 +374,28 @@ def main():
                         sa_centers=nx9.transpose(1, 2).contiguous().numpy(), sa_features=nf9.transpose(1, 2).contiguous().numpy(),
                         tokens_in=tok9.numpy(), tokens_out=y9.numpy())
     print('g9 ppat', y9.shape)
+    # ---- G10: full-covariance DOTA (dota.py:19-87; `import clip` at :8 is unused, so only the class is compiled) ----
+    ns10 = {'torch': torch, 'nn': nn}
+    _exec_defs(os.path.join(REF, 'dota.py'), ['DOTA'], ns10)
+    K10, D10, n10 = 8, 256, 12
+    g10 = torch.Generator().manual_seed(31)
+    text10 = torch.nn.functional.normalize(torch.randn(K10, D10, generator=g10), dim=1)
+    cfg10 = {'epsilon': 1e-4, 'sigma': 1e-4}
+    ref10 = ns10['DOTA'](cfg10, D10, K10, text10.T.clone())
+    lab10 = torch.randint(0, K10, (n10,), generator=g10)
+    X10 = torch.nn.functional.normalize(text10[lab10] + 0.35 * torch.randn(n10, D10, generator=g10), dim=1)
+    Y10 = torch.softmax(100.0 * X10 @ text10.T, dim=1)
+    sc10 = []
+    for i in range(n10):
+        sc10.append(ref10.predict(X10[i:i + 1].half()).float())
+        ref10.fit(X10[i:i + 1], Y10[i:i + 1]); ref10.update()
+    ref10.fit(X10[:3], Y10[:3]); ref10.update()                              # one batched fit (B = 3)
+    sb10 = ref10.predict(X10[3:5].half()).float()
+    np.savez_compressed(os.path.join(OUT, 'g10_dota_fullcov.npz'), text=text10.numpy(), X=X10.numpy(), Y=Y10.numpy(), eps=np.float64(1e-4),
+                        sigma=np.float64(1e-4), scores=torch.cat(sc10).numpy(), scores_after_batch=sb10.numpy(), mu=ref10.mu.numpy(),
+                        c=ref10.c.numpy(), Sigma0=ref10.Sigma[0].numpy(), overall_Sigma=ref10.overall_Sigma.numpy(),
+                        Lambda=ref10.Lambda.float().numpy())
+    print('g10 dota full covariance', torch.cat(sc10).shape)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

@@ -667,6 +667,49 @@ def make_ppat_state_dict(seed: int, dim: int = 512, depth: int = 12, heads: int 
 
 
 # ======================================================================================
+# F2  full-covariance DOTA (dota.py:19-87)
+# ======================================================================================
+class DotaFull:
+    """dota.py:19-87 restated (no prior option): per-class full covariance, shared precision matrix,
+    fp16 scoring.  `dtype` = torch.float32 follows the reference arithmetic (incl. its .half() casts);
+    torch.float64 keeps everything in double (no half casts) as the truth for error budgets."""
+
+    def __init__(self, cfg, input_shape, num_classes, clip_weights, dtype=torch.float32):
+        self.D, self.K, self.eps, self.dtype = input_shape, num_classes, cfg['epsilon'], dtype
+        self.mu = clip_weights.T.to(dtype).clone()                                        # :27
+        self.c = torch.ones(num_classes, dtype=dtype)                                     # :28
+        self.Sigma = (cfg['sigma'] * torch.eye(input_shape, dtype=dtype)).repeat(num_classes, 1, 1)   # :29
+        self.overall_Sigma = self.Sigma.mean(0)                                           # :30
+        self.Lambda = self._cast(torch.pinverse(self.overall_Sigma.double()))             # :31
+
+    def _cast(self, t):
+        return t.half() if self.dtype == torch.float32 else t.to(self.dtype)
+
+    def fit(self, x, y):                                                                  # :42-66
+        x, y = x.to(self.dtype), y.to(self.dtype)
+        sw = y.sum(0)
+        wx = y.T @ x
+        new_mu = (wx + self.c[:, None] * self.mu) / (sw[:, None] + self.c[:, None])
+        new_c = self.c + sw
+        d = x[:, None, :] - self.mu[None]                                                 # uses the OLD mean (:56)
+        delta = torch.einsum('bji,bjk->jik', y[:, :, None] * d, d)
+        self.Sigma = (self.c[:, None, None] * self.Sigma + delta) / (self.c[:, None, None] + sw[:, None, None])
+        self.overall_Sigma = self.Sigma.mean(0)
+        self.mu, self.c = new_mu, new_c
+
+    def update(self):                                                                     # :69-72
+        A = (1 - self.eps) * self.overall_Sigma + self.eps * torch.eye(self.D, dtype=self.dtype)
+        self.Lambda = self._cast(torch.inverse(A))
+
+    def predict(self, X):                                                                 # :75-86
+        L = self.Lambda
+        M = self._cast(self.mu.T)
+        W = L @ M
+        c = 0.5 * (M * W).sum(0)
+        return self._cast(X) @ W - c
+
+
+# ======================================================================================
 # A14  per-sample loop (cache part; encoder outputs are inputs)
 # ======================================================================================
 @dataclass

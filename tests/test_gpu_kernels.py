@@ -642,3 +642,68 @@ def test_align_step_fused_is_bit_identical_to_the_three_kernels(ua, golden_dir, 
         for x, y in zip(A, B):
             assert torch.equal(x, y), step
         assert int(tickets.abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ full-covariance DOTA (section 8 row F2)
+def test_dota_full_covariance_stream_vs_reference_fixture(ua, golden_dir):
+    """uni_adapter_amd.dota.DOTA (HIP) on the stream of g10 - the reference class's own outputs.  fp32 state within
+    fp32 noise; Lambda and the scores are fp16 tensors: almost all entries identical, the rest one fp16 ulp apart."""
+    from uni_adapter_amd.dota import DOTA
+    g = _load(golden_dir, 'g10_dota_fullcov.npz')
+    text, X, Y = _t(g['text']), _t(g['X']), _t(g['Y'])
+    K, D = text.shape
+    m = DOTA({'epsilon': float(g['eps']), 'sigma': float(g['sigma'])}, D, K, text.T.clone())
+    truth = O.DotaFull({'epsilon': float(g['eps']), 'sigma': float(g['sigma'])}, D, K, text.T.clone(), dtype=torch.float64)
+    sc = []
+    for i in range(X.shape[0]):
+        sc.append(m.predict(X[i:i + 1].half()).float().cpu())
+        m.fit(X[i:i + 1], Y[i:i + 1]); m.update()
+        truth.fit(X[i:i + 1], Y[i:i + 1]); truth.update()
+    m.fit(X[:3], Y[:3]); m.update()
+    truth.fit(X[:3], Y[:3]); truth.update()
+    sb = m.predict(X[3:5].half()).float().cpu()
+    # fp32 state
+    assert (m.mu.cpu() - _t(g['mu'])).abs().max().item() < 1e-6
+    assert torch.equal(m.c.cpu(), _t(g['c'])) or (m.c.cpu() - _t(g['c'])).abs().max().item() < 1e-6
+    s0 = _t(g['Sigma0'])
+    assert (m.Sigma[0].cpu() - s0).abs().max().item() <= 2e-6 * s0.abs().max().item()
+    ov = _t(g['overall_Sigma'])
+    assert (m.overall_Sigma.cpu() - ov).abs().max().item() <= 2e-6 * ov.abs().max().item()
+    # the inverse: against the fp64 truth no worse than the reference's own fp32 LU (both before fp16 rounding would differ
+    # by ~1e-5 relative; after rounding compare in fp16 ulps)
+    Lr, Lm = _t(g['Lambda']), m.Lambda.float().cpu()
+    eL = (Lm.double() - truth.Lambda).abs().max().item(); eR = (Lr.double() - truth.Lambda).abs().max().item()
+    scale = truth.Lambda.abs().max().item()
+    # both are fp16 roundings of fp32 inverses: error against the fp64 inverse = fp16 half-ulp of the large entries
+    # (2^-11 relative) + the fp32 solver's own error; ours may not be worse than the reference's LU by more than noise
+    assert eL <= eR + 1e-4 * scale, (eL, eR, scale)
+    assert (Lm - Lr).abs().max().item() <= 2.0 * eR + 1e-4 * scale, ((Lm - Lr).abs().max().item(), eR, scale)
+    # scores = half(X W) - c: a difference of two fp16 numbers of magnitude ~5e3 (fp16 spacing 4 there), so the
+    # comparison is absolute: within one such step, and the same arg-max
+    S, Sr = torch.cat(sc), _t(g['scores'])
+    step = 2.0 ** (torch.floor(torch.log2(Sr.abs().max())).item() - 10)
+    assert (S - Sr).abs().max().item() <= step, ((S - Sr).abs().max().item(), step)
+    assert (S != Sr).float().mean().item() < 0.25
+    assert torch.equal(S.argmax(1), Sr.argmax(1))
+    sbr = _t(g['scores_after_batch'])
+    assert (sb - sbr).abs().max().item() <= step and torch.equal(sb.argmax(1), sbr.argmax(1))
+
+
+@pytest.mark.parametrize('n', [64, 192, 512])
+def test_blocked_spd_inverse(ua, n):
+    """ua_spd_inverse_small + the Schur-complement recursion on ua_gemm against fp64 inversion."""
+    from uni_adapter_amd.dota import DOTA
+    g = torch.Generator().manual_seed(n)
+    text = torch.nn.functional.normalize(torch.randn(4, n, generator=g), dim=1)
+    m = DOTA({'epsilon': 1e-4, 'sigma': 1e-4}, n, 4, text.T.clone())
+    Q = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = (Q @ Q.T) / n + 0.05 * torch.eye(n, dtype=torch.float64)          # SPD, condition number ~ 1e2
+    Ad = dev(A.float()); out = torch.empty(n, n, device='cuda')
+    m._A.copy_(Ad); m._dirty = True
+    m.update()                                   # block inverse + Newton-Schulz refinement; m._inv is the fp32 result
+    out = m._inv
+    ref = torch.linalg.inv(A)
+    ref32 = torch.linalg.inv(A.float())
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= max(4.0 * (ref32.double() - ref).abs().max().item(), 1e-5 * ref.abs().max().item()), err
+    assert (out @ Ad - torch.eye(n, device='cuda')).abs().max().item() < 5e-4

@@ -202,3 +202,21 @@ def test_g9_openshape_ppat_parts(golden_dir):
     assert np.abs(sa.numpy() - g['sa_features']).max() < 2e-6
     y = O.ppat_transformer(torch.from_numpy(g['tokens_in']), sd, 8)
     assert np.abs(y.numpy() - g['tokens_out']).max() < 2e-5
+
+
+def test_g10_full_covariance_dota_is_bit_exact(golden_dir):
+    """Oracle restatement of dota.py (per-class full covariance, shared precision, fp16 scores) vs the
+    reference class run on a 12-sample stream + one batched fit: every tensor identical."""
+    g = _load(golden_dir, 'g10_dota_fullcov.npz')
+    text, X, Y = (torch.from_numpy(g[k]) for k in ('text', 'X', 'Y'))
+    m = O.DotaFull({'epsilon': float(g['eps']), 'sigma': float(g['sigma'])}, X.shape[1], text.shape[0], text.T.clone())
+    sc = []
+    for i in range(X.shape[0]):
+        sc.append(m.predict(X[i:i + 1].half()).float())
+        m.fit(X[i:i + 1], Y[i:i + 1]); m.update()
+    m.fit(X[:3], Y[:3]); m.update()
+    assert np.array_equal(torch.cat(sc).numpy(), g['scores'])
+    assert np.array_equal(m.predict(X[3:5].half()).float().numpy(), g['scores_after_batch'])
+    assert np.array_equal(m.mu.numpy(), g['mu']) and np.array_equal(m.c.numpy(), g['c'])
+    assert np.array_equal(m.Sigma[0].numpy(), g['Sigma0']) and np.array_equal(m.overall_Sigma.numpy(), g['overall_Sigma'])
+    assert np.array_equal(m.Lambda.float().numpy(), g['Lambda'])

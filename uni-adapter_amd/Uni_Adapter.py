@@ -347,6 +347,41 @@ class TtaEngine:
         return {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}
 
 
+def _run_full_covariance_dota(test_loader, model, args):
+    """`--use-dota` without `--use-mode-dota` (Uni_Adapter.py:328-332,409-412): full-covariance DOTA, one sample at a
+    time.  The reference never assigns `final_logits` on this branch (it cannot run it); the fusion here is the rule
+    of the usage note dota_mixture.py:288-293, final = clip + clamp(rho * mean(c) / batch, max=eta) * dota."""
+    from .dota import DOTA
+    dev = torch.device(args.device if getattr(args, 'device', None) else 'cuda')
+    ptf = getattr(args, 'precomputed_text_features', None)
+    text = ptf if isinstance(ptf, torch.Tensor) else torch.load(ptf, map_location='cpu', weights_only=True)
+    text = text.to(dev, torch.float32).contiguous()                                    # (K,D)
+    K, D = text.shape
+    cfg = {'epsilon': args.dota_epsilon, 'sigma': args.dota_sigma, 'eta': args.dota_eta, 'rho': args.dota_rho}
+    dota = DOTA(cfg, D, K, torch.full((D, K), 0.001), prior_pre_steps=getattr(args, 'dota_prior_pre_steps', None), device=dev)   # :329-330
+    model.eval()
+    correct = torch.zeros(3, dtype=torch.int64, device=dev)
+    count = 0
+    fh = torch.empty(1, D, device=dev); z = torch.empty(1, K, device=dev); prob = torch.empty(1, K, device=dev)
+    for pc, target, _, rgb in test_loader:
+        pc, rgb, target = torch.as_tensor(pc), torch.as_tensor(rgb), torch.as_tensor(target).reshape(-1)
+        feats = model.encode_pc(torch.cat((pc.float(), rgb.float()), -1).to(dev))
+        for j in range(feats.shape[0]):
+            lib.call('ua_clip_logits', lib.ptr(feats[j:j + 1].contiguous()), lib.ptr(text), K, D, LOGIT_SCALE, 1, lib.ptr(fh), lib.ptr(z),
+                     lib.ptr(prob), None, None, lib.stream_ptr())                       # :406
+            dz = dota.predict(fh.half())                                              # :410
+            dota.fit(fh, prob); dota.update()                                         # :411-412
+            final = dota.fuse(z, dz, 1, cfg['rho'], cfg['eta'])
+            rank = (final[0] > final[0, int(target[j])]).sum()
+            correct += torch.stack([(rank < k) for k in (1, 3, 5)]).to(torch.int64)
+            count += 1
+    c = correct.tolist()
+    d = max(1, count)
+    acc = {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}
+    logging.info(f"Final Results: Acc@1 {acc['acc1']:.3f} Acc@3 {acc['acc3']:.3f} Acc@5 {acc['acc5']:.3f}")
+    return acc
+
+
 # ----------------------------------------------------------------------------- entry point
 def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model, tokenizer, args, hp):
     """Same signature and return value as Uni_Adapter.py:272-595.  `test_loader` yields
@@ -354,7 +389,9 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
     Extra optional attributes read from `args` (never required):
       chunk_size (16), aug_noise (callable(sample_index0, pc) -> noise, for reproducible streams)."""
     if not getattr(args, 'use_mode_dota', True):
-        raise NotImplementedError('only the --use-mode-dota path is built (the reference CLI cannot reach the others)')
+        if getattr(args, 'use_dota', False):
+            return _run_full_covariance_dota(test_loader, model, args)
+        raise NotImplementedError('the original cluster cache (neither --use-dota nor --use-mode-dota) is not built (SURVEY section 8 row F3)')
     model.eval()
     dota_cfg = {'epsilon': args.dota_epsilon, 'sigma': args.dota_sigma, 'eta': args.dota_eta, 'rho': args.dota_rho}
     logging.info(f"MODE DOTA Hyperparameters: {dota_cfg}")

@@ -45,6 +45,9 @@ def parse_args(argv=None):
     p.add_argument('--dota-eta', type=float, default=0.1)
     p.add_argument('--dota-rho', type=float, default=0.02)
     p.add_argument('--use-mode-dota', action='store_true', default=True)
+    p.add_argument('--no-use-mode-dota', dest='use_mode_dota', action='store_false', help='with --use-dota: the full-covariance DOTA cache (dota.py)')
+    p.add_argument('--use-dota', action='store_true', default=False)
+    p.add_argument('--dota-prior_pre_steps', type=int, default=None)
     p.add_argument('--mode-M', type=int, default=4)
     p.add_argument('--res-learning', action='store_true', default=True)
     p.add_argument('--no-res-learning', dest='res_learning', action='store_false')
