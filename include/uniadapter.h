@@ -301,6 +301,26 @@ int ua_to_half(const float* x, void* y_half, int64_t n, void* stream);
 int ua_dota_predict(const void* Lambda_half, const float* mu, const void* X_half, int32_t B, int32_t K, int32_t D,
                     void* W_half, float* scores, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Original Uni-Adapter cluster cache (Uni_Adapter.py:78-156,541-574; utils/math_utils.py:21-95).
+ * ua_cluster_merge (:93-116): the n_slots prototypes of ONE (full) class - keys (n,D), conf (n), count (n) int32,
+ *   prob (n,K) - absorb the unit feature f with confidence *conf_new into the most similar prototype; the prototype's
+ *   prob / confidence are recomputed from 100 * key @ text^T (text (K,D)).
+ * ua_cluster_laplacian (math_utils.py:50-58): W (P,P) = normalised keys @ keys^T in, L_reg = I - S W' S + 2 lambda I out
+ *   (W' = W with entries < threshold zeroed, S = diag(1/(sqrt(rowsum W') + 1e-8))); scratch_s: P floats.
+ * ua_cluster_cg_step (math_utils.py:31-43): one conjugate-gradient iteration after ApT = pT @ A^T (ua_gemm); all
+ *   vectors transposed, (K right-hand sides, P) with row pitch ld (>= P, zero padding; ld % 4 == 0 for the GEMM); sets *not_done if any residual norm^2 >= tol.
+ * ua_cluster_logits (:148-156, :552-574): prototype classes from the refined values xT (K,P), affinity f . keys,
+ *   cache_logits (K, optional) and final = softmax(clip/100)/H1 + softmax(cache_logits)/H2 (K).
+ * ------------------------------------------------------------------------------------------ */
+int ua_cluster_merge(float* keys, float* conf, int32_t* count, float* prob, const float* f, const float* conf_new,
+                     const float* text, int32_t n_slots, int32_t K, int32_t D, float beta, void* stream);
+int ua_cluster_laplacian(float* W, int32_t P, int32_t ld, float threshold, float lambda_reg, float* scratch_s, void* stream);
+int ua_cluster_cg_step(float* xT, float* rT, float* pT, const float* ApT, float* rz_old, int32_t K, int32_t P, int32_t ld, float tol,
+                       int32_t* not_done, void* stream);
+int ua_cluster_logits(const float* xT, int32_t ld, const float* keys, const float* f, const float* clip_logits, int32_t P, int32_t K, int32_t D,
+                      int32_t* cls_scratch, float* aff_scratch, float* cache_logits, float* final_logits, void* stream);
+
 /* PointBERT / ULIP-2 variant (models/ulip/pointbert/point_encoder.py:95-98,173-192):
  * ua_add_pos: x += pos before every block (patch rows get pos[b*G+g], CLS rows cls_pos).
  * ua_cls_max_concat: out (Bc, 2C) = [x_cls | max over the G patch tokens] (:190).                */

@@ -396,6 +396,39 @@ def main():
                         c=ref10.c.numpy(), Sigma0=ref10.Sigma[0].numpy(), overall_Sigma=ref10.overall_Sigma.numpy(),
                         Lambda=ref10.Lambda.float().numpy())
     print('g10 dota full covariance', torch.cat(sc10).shape)
+    # ---- G11: original cluster cache + graph refinement (Uni_Adapter.py:78-156,541-574; utils/math_utils.py imported as is) ----
+    import importlib.util
+    spec11 = importlib.util.spec_from_file_location('ref_math_utils', os.path.join(REF, 'utils', 'math_utils.py'))
+    mu11 = importlib.util.module_from_spec(spec11); spec11.loader.exec_module(mu11)
+    ns11 = {'torch': torch, 'F': F, 'np': np, 'math_utils': mu11}
+    _exec_defs(os.path.join(REF, 'Uni_Adapter.py'), ['softmax_entropy', 'get_entropy', 'update_cache', 'compute_cache_logits'], ns11)
+    K11, D11, n11, cap11 = 6, 256, 40, 3
+    g11 = torch.Generator().manual_seed(77)
+    text11 = torch.nn.functional.normalize(torch.randn(K11, D11, generator=g11), dim=1)
+    lab11 = torch.randint(0, K11, (n11,), generator=g11)
+    feats11 = text11[lab11] + 0.9 * torch.randn(n11, D11, generator=g11) / 16
+    hp11 = {'shot_capacity': cap11, 'beta': 150, 'threshold': 0.5, 'lambda_reg': 0.11}
+    cw11 = text11.T.contiguous()
+    cache11, Lo11, Li11 = {}, 0, 0
+    fin11, z211 = [], []
+    for i in range(n11):                                                       # the statements of the loop body :406, :541-574
+        pcf = feats11[i:i + 1] / feats11[i:i + 1].norm(dim=-1, keepdim=True)
+        cl = 100. * pcf @ cw11
+        loss = ns11['softmax_entropy'](cl); pm = cl.softmax(1)
+        pred = int(cl.topk(1, dim=1)[1].t()[0])
+        pe = torch.tensor(ns11['get_entropy'](loss, cw11))
+        add = ns11['update_cache'](cache11, pred, [pcf, loss, pe, pm], shot_capacity=cap11, clip_weights=cw11, beta=150)
+        fl = cl.clone() / 100.0
+        p1 = torch.softmax(fl, dim=1); e1 = ns11['softmax_entropy'](p1, False)
+        fl2, info = ns11['compute_cache_logits'](pcf, cache11, cw11, [add, Lo11, Li11], i, hp11)
+        Lo11, Li11 = info[0], info[1]
+        p2 = torch.softmax(fl2, dim=1); e2 = ns11['softmax_entropy'](p2, False)
+        fin11.append((1 / e1).reshape(-1, 1) * p1 + (1 / e2).reshape(-1, 1) * p2); z211.append(fl2)
+    keys11 = torch.cat([it[0] for c in sorted(cache11) for it in cache11[c]], 0)
+    np.savez_compressed(os.path.join(OUT, 'g11_cluster_cache.npz'), text=text11.numpy(), feats=feats11.numpy(), cap=np.int64(cap11), beta=np.float64(150),
+                        threshold=np.float64(0.5), lambda_reg=np.float64(0.11), finals=torch.cat(fin11).numpy(), cache_logits=torch.cat(z211).numpy(),
+                        final_keys=keys11.numpy(), final_counts=np.array([it[3] for c in sorted(cache11) for it in cache11[c]], dtype=np.int64))
+    print('g11 cluster cache', keys11.shape)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

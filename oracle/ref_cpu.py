@@ -710,6 +710,97 @@ class DotaFull:
 
 
 # ======================================================================================
+# F3  original Uni-Adapter cluster cache + graph label refinement (Uni_Adapter.py:78-150,541-574; utils/math_utils.py)
+# ======================================================================================
+def conjugate_gradient(A, b, tol=1e-5, max_iter=100):
+    """utils/math_utils.py:21-45 (no preconditioner, x0 = 0); returns (x, iterations run)."""
+    x = torch.zeros_like(b)
+    r = b - A @ x
+    p = r.clone()
+    rz_old = (r * r).sum(0)
+    it = 0
+    for it in range(1, max_iter + 1):
+        Ap = A @ p
+        alpha = (rz_old / ((p * Ap).sum(0) + 1e-8)).view(1, -1)
+        x = x + alpha * p
+        r = r - alpha * Ap
+        rz_new = (r * r).sum(0)
+        if torch.all(rz_new < tol):
+            break
+        beta = (rz_new / (rz_old + 1e-8)).view(1, -1)
+        p = r + beta * p
+        rz_old = rz_new
+    return x, it
+
+
+def refine_values(cache_keys, all_probs, threshold, lambda_reg):
+    """utils/math_utils.py:48-95 (`online_value_refinement_new`, the CG path)."""
+    nk = F.normalize(cache_keys, p=2, dim=1)
+    W = nk @ nk.T
+    W[W < threshold] = 0
+    dis = torch.diag(1.0 / (torch.sqrt(W.sum(dim=1)) + 1e-8))
+    L_reg = (torch.eye(W.size(0), dtype=W.dtype) - dis @ W @ dis) + 2 * lambda_reg * torch.eye(W.size(0), dtype=W.dtype)
+    x, it = conjugate_gradient(L_reg, 2 * lambda_reg * all_probs)
+    return x / x.sum(1).unsqueeze(1), L_reg, it
+
+
+class ClusterCache:
+    """The single cluster cache of the original Uni-Adapter (Uni_Adapter.py:78-118,120-156,541-574): per predicted class up to
+    `shot_capacity` prototypes [feature, confidence, prob, count]; a full class merges the new sample into its most similar
+    prototype (confidence-weighted).  `step` = one pass of the loop body of the `not use_dota and not use_mode_dota` branch."""
+
+    def __init__(self, text_kd, shot_capacity=30, beta=150.0, threshold=0.5, lambda_reg=0.11, dtype=torch.float32):
+        self.text = text_kd.to(dtype)                      # (K,D); the reference carries clip_weights = text^T (D,K), contiguous
+        self.cw = self.text.T.contiguous()
+        self.cap, self.beta, self.thr, self.lam, self.dtype = shot_capacity, beta, threshold, lambda_reg, dtype
+        self.cache: Dict[int, list] = {}
+        self.last_cg_iterations = 0
+
+    def _conf(self, z):
+        prop = softmax_entropy(z) / math.log2(self.text.shape[0])       # get_entropy (:28-30): loss / log2(K)
+        return torch.exp(-self.beta * prop)
+
+    def update(self, pred, f, prob, ent):                                # update_cache :78-118
+        conf = torch.exp(-self.beta * (ent / math.log2(self.text.shape[0])))
+        if pred in self.cache:
+            if len(self.cache[pred]) < self.cap:
+                self.cache[pred].append([f, conf, prob, 1])
+                return True
+            sims = torch.stack([f @ it[0].T for it in self.cache[pred]])
+            mi = int(torch.argmax(sims))
+            fc, cc, _, nc = self.cache[pred][mi]
+            nf = (cc * nc * fc + conf * f) / (nc * cc + conf)
+            nf = nf / nf.norm(dim=-1, keepdim=True)
+            z = 100 * nf @ self.cw
+            self.cache[pred][mi] = [nf, self._conf(z), torch.softmax(z, dim=1), nc + 1]
+            return False
+        self.cache[pred] = [[f, conf, prob, 1]]
+        return True
+
+    def cache_logits(self, f):                                           # compute_cache_logits :120-156
+        keys = torch.cat([it[0] for c in sorted(self.cache) for it in self.cache[c]], 0)
+        probs = torch.cat([it[2] for c in sorted(self.cache) for it in self.cache[c]], 0)
+        new, _, self.last_cg_iterations = refine_values(keys, probs, self.thr, self.lam)
+        cls = new.argmax(1)
+        vals = F.one_hot(cls, num_classes=self.text.shape[0]).to(self.dtype)
+        vals = vals / (vals.sum(0) + 1e-6)
+        return (F.normalize(f, dim=-1) @ keys.T) @ vals
+
+    def step(self, feat):
+        feat = feat.to(self.dtype)
+        f = feat / feat.norm(dim=-1, keepdim=True)                       # get_logits_wrapper :55-57
+        z = 100.0 * f @ self.cw
+        ent, prob, pred = softmax_entropy(z), z.softmax(1), int(z.argmax(1))
+        self.update(pred, f, prob, ent)
+        p1 = torch.softmax(z / 100.0, dim=1)                             # :552-554
+        e1 = -(p1 * torch.log(p1 + 1e-10)).sum(1)
+        z2 = self.cache_logits(f)
+        p2 = torch.softmax(z2, dim=1)                                    # :570-572
+        e2 = -(p2 * torch.log(p2 + 1e-10)).sum(1)
+        return (1 / e1).reshape(-1, 1) * p1 + (1 / e2).reshape(-1, 1) * p2, z2
+
+
+# ======================================================================================
 # A14  per-sample loop (cache part; encoder outputs are inputs)
 # ======================================================================================
 @dataclass

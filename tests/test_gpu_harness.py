@@ -305,3 +305,27 @@ def test_use_dota_branch_runs_the_full_covariance_cache():
         final = z + w * dz
         hits += int(final.argmax()) == int(tgt[i])
     assert abs(acc['acc1'] - 100.0 * hits / n) < 1e-6
+
+
+def test_cluster_cache_branch_of_the_harness():
+    """Neither --use-dota nor --use-mode-dota: the original cluster cache through test_zeroshot_3d_core vs the oracle loop."""
+    import types
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import get_hyperparams, test_zeroshot_3d_core as core
+    D, K, n = 256, 5, 12
+    model = create_uni3d_from_state_dict(synthetic.uni3d_state_dict(9, trans_dim=128, embed_dim=D, depth=1, device='cuda'), num_group=128,
+                                         group_size=64, num_heads=2, device='cuda')
+    xyz, rgb = synthetic.point_clouds(n, 1024, seed=11)
+    text = synthetic.text_bank(K, D, seed=5)
+    tgt = torch.arange(n) % K
+    loader = [(xyz[i:i + 3], tgt[i:i + 3], ['x'] * 3, rgb[i:i + 3]) for i in range(0, n, 3)]
+    hp = dict(get_hyperparams('modelnet'), shot_capacity=2)
+    assert get_hyperparams('ShapeNetCore')['use_new_approximation'] is False and get_hyperparams('scanobjectnn')['lambda_reg'] == 0.20
+    args = types.SimpleNamespace(use_mode_dota=False, use_dota=False, device='cuda', precomputed_text_features=text, vlm3d='uni3d',
+                                 dataset_name='modelnet')
+    acc = core(loader, 'x', model, None, None, args, hp)
+    feats = model.encode_pc(torch.cat([xyz, rgb], -1).cuda()).cpu()
+    oc = O.ClusterCache(text, 2, 150.0, 0.5, 0.11)
+    hits = sum(int(oc.step(feats[i:i + 1])[0].argmax()) == int(tgt[i]) for i in range(n))
+    assert abs(acc['acc1'] - 100.0 * hits / n) < 1e-6

@@ -707,3 +707,28 @@ def test_blocked_spd_inverse(ua, n):
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= max(4.0 * (ref32.double() - ref).abs().max().item(), 1e-5 * ref.abs().max().item()), err
     assert (out @ Ad - torch.eye(n, device='cuda')).abs().max().item() < 5e-4
+
+
+# ------------------------------------------------------------------ original cluster cache (section 8 row F3)
+def test_cluster_cache_stream_vs_reference_fixture(ua, golden_dir):
+    """uni_adapter_amd.uni_cache.ClusterCache (HIP) on the stream of g11 - outputs of the reference's own functions."""
+    from uni_adapter_amd.uni_cache import ClusterCache
+    g = _load(golden_dir, 'g11_cluster_cache.npz')
+    text, feats = _t(g['text']), _t(g['feats'])
+    hp = {'shot_capacity': int(g['cap']), 'beta': float(g['beta']), 'threshold': float(g['threshold']), 'lambda_reg': float(g['lambda_reg'])}
+    c = ClusterCache(text, hp)
+    fin, z2 = [], []
+    for i in range(feats.shape[0]):
+        f, z = c.step(feats[i:i + 1])
+        fin.append(f.cpu()); z2.append(z.cpu())
+        assert c.last_cg_iterations <= 10
+    fin, z2 = torch.cat(fin), torch.cat(z2)
+    rf, rz = _t(g['finals']), _t(g['cache_logits'])
+    assert (z2 - rz).abs().max().item() <= 2e-6 * max(1.0, rz.abs().max().item())
+    assert (fin - rf).abs().max().item() <= 1e-5 * rf.abs().max().item()
+    assert torch.equal(fin.argmax(1), rf.argmax(1))
+    idx = c._idx.cpu()
+    assert (c.keys.cpu()[idx] - _t(g['final_keys'])).abs().max().item() < 1e-6
+    assert c.count.cpu()[idx].tolist() == g['final_counts'].tolist()
+    with pytest.raises(NotImplementedError):
+        ClusterCache(text, dict(hp, use_new_approximation=False))

@@ -220,3 +220,17 @@ def test_g10_full_covariance_dota_is_bit_exact(golden_dir):
     assert np.array_equal(m.mu.numpy(), g['mu']) and np.array_equal(m.c.numpy(), g['c'])
     assert np.array_equal(m.Sigma[0].numpy(), g['Sigma0']) and np.array_equal(m.overall_Sigma.numpy(), g['overall_Sigma'])
     assert np.array_equal(m.Lambda.float().numpy(), g['Lambda'])
+
+
+def test_g11_cluster_cache_is_bit_exact(golden_dir):
+    """Oracle restatement of the original cluster cache (prototype merge, graph refinement by CG, combination) vs the
+    reference's own update_cache / compute_cache_logits / math_utils on a 40-sample stream (capacity 3 -> merges)."""
+    g = _load(golden_dir, 'g11_cluster_cache.npz')
+    text, feats = torch.from_numpy(g['text']), torch.from_numpy(g['feats'])
+    c = O.ClusterCache(text, int(g['cap']), float(g['beta']), float(g['threshold']), float(g['lambda_reg']))
+    for i in range(feats.shape[0]):
+        final, z2 = c.step(feats[i:i + 1])
+        assert np.array_equal(final.numpy(), g['finals'][i:i + 1]) and np.array_equal(z2.numpy(), g['cache_logits'][i:i + 1]), i
+    keys = torch.cat([it[0] for k in sorted(c.cache) for it in c.cache[k]], 0)
+    assert np.array_equal(keys.numpy(), g['final_keys'])
+    assert [it[3] for k in sorted(c.cache) for it in c.cache[k]] == g['final_counts'].tolist()

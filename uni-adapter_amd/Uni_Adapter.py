@@ -382,6 +382,46 @@ def _run_full_covariance_dota(test_loader, model, args):
     return acc
 
 
+def get_hyperparams(dataset_name):
+    """utils/hyperparams.py:1-38 (values of the paper's settings)."""
+    params = {'shot_capacity': 30, 'beta': 150, 'threshold': 0.5, 'lambda_reg': 0.11, 'use_new_approximation': True}
+    name = dataset_name.lower()
+    if 'scanobject' in name:
+        params['lambda_reg'] = 0.20
+    elif 'shapenet' in name:
+        params.update(lambda_reg=0.07, threshold=0.45, use_new_approximation=False)
+    return params
+
+
+def _run_cluster_cache(test_loader, model, args, hp):
+    """Neither --use-dota nor --use-mode-dota: the original Uni-Adapter cluster cache (Uni_Adapter.py:357-361,541-574), one
+    sample at a time.  The refinement follows `args.use_new_approximation` (default True: conjugate gradients), as the
+    reference's loop does (:557), not the per-dataset `hp` entry."""
+    from .uni_cache import ClusterCache
+    dev = torch.device(args.device if getattr(args, 'device', None) else 'cuda')
+    ptf = getattr(args, 'precomputed_text_features', None)
+    text = ptf if isinstance(ptf, torch.Tensor) else torch.load(ptf, map_location='cpu', weights_only=True)
+    hp = dict(hp if hp is not None else get_hyperparams(getattr(args, 'dataset_name', 'modelnet')))
+    hp['use_new_approximation'] = bool(getattr(args, 'use_new_approximation', True))
+    cache = ClusterCache(text, hp, device=dev)
+    model.eval()
+    correct = torch.zeros(3, dtype=torch.int64, device=dev)
+    count = 0
+    for pc, target, _, rgb in test_loader:
+        pc, rgb, target = torch.as_tensor(pc), torch.as_tensor(rgb), torch.as_tensor(target).reshape(-1)
+        feats = model.encode_pc(torch.cat((pc.float(), rgb.float()), -1).to(dev))
+        for j in range(feats.shape[0]):
+            final, _ = cache.step(feats[j:j + 1])
+            rank = (final[0] > final[0, int(target[j])]).sum()
+            correct += torch.stack([(rank < k) for k in (1, 3, 5)]).to(torch.int64)
+            count += 1
+    c = correct.tolist()
+    d = max(1, count)
+    acc = {'acc1': 100.0 * c[0] / d, 'acc3': 100.0 * c[1] / d, 'acc5': 100.0 * c[2] / d}
+    logging.info(f"Final Results: Acc@1 {acc['acc1']:.3f} Acc@3 {acc['acc3']:.3f} Acc@5 {acc['acc5']:.3f}")
+    return acc
+
+
 # ----------------------------------------------------------------------------- entry point
 def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model, tokenizer, args, hp):
     """Same signature and return value as Uni_Adapter.py:272-595.  `test_loader` yields
@@ -391,7 +431,7 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
     if not getattr(args, 'use_mode_dota', True):
         if getattr(args, 'use_dota', False):
             return _run_full_covariance_dota(test_loader, model, args)
-        raise NotImplementedError('the original cluster cache (neither --use-dota nor --use-mode-dota) is not built (SURVEY section 8 row F3)')
+        return _run_cluster_cache(test_loader, model, args, hp)
     model.eval()
     dota_cfg = {'epsilon': args.dota_epsilon, 'sigma': args.dota_sigma, 'eta': args.dota_eta, 'rho': args.dota_rho}
     logging.info(f"MODE DOTA Hyperparameters: {dota_cfg}")

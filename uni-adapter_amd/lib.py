@@ -61,6 +61,10 @@ SIGNATURES = {
     'ua_align_backward': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
     'ua_residual_adam': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _d, _d, _d, _d, _p],
     'ua_align_step': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _d, _d, _d, _d, _p, _p, _p, _p, _p],
+    'ua_cluster_merge': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p],
+    'ua_cluster_laplacian': [_p, _i32, _i32, _f, _f, _p, _p],
+    'ua_cluster_cg_step': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p],
+    'ua_cluster_logits': [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     'ua_dota_fit': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p],
     'ua_spd_inverse_small': [_p, _i64, _i32, _p, _i64, _p],
     'ua_to_half': [_p, _p, _i64, _p],

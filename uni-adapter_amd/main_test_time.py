@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .tta_data import CORRUPTIONS, load_point_encoder, load_tta_dataset
-from .Uni_Adapter import test_zeroshot_3d_core
+from .Uni_Adapter import get_hyperparams, test_zeroshot_3d_core
 
 
 def parse_args(argv=None):
@@ -48,6 +48,7 @@ def parse_args(argv=None):
     p.add_argument('--no-use-mode-dota', dest='use_mode_dota', action='store_false', help='with --use-dota: the full-covariance DOTA cache (dota.py)')
     p.add_argument('--use-dota', action='store_true', default=False)
     p.add_argument('--dota-prior_pre_steps', type=int, default=None)
+    p.add_argument('--use-new-approximation', default=True, type=bool)
     p.add_argument('--mode-M', type=int, default=4)
     p.add_argument('--res-learning', action='store_true', default=True)
     p.add_argument('--no-res-learning', dest='res_learning', action='store_false')
@@ -75,6 +76,8 @@ def run(args, model=None):
     logging.info(f'Args: {args}')
     if model is None:
         model = load_point_encoder(args, device=args.device)
+    hp = get_hyperparams(args.dataset_name)                                                       # main_test-time.py:42-43
+    logging.info(f'Hyperparameters: {hp}')
     corruptions = CORRUPTIONS if args.corruption == 'all' else [args.corruption]
     results = {}
     for corr in corruptions:
@@ -84,7 +87,7 @@ def run(args, model=None):
         loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.workers,
                                              pin_memory=True, drop_last=False)
         result = test_zeroshot_3d_core(test_loader=loader, validate_dataset_name=args.validate_dataset_name, model=model,
-                                       clip_model=None, tokenizer=None, args=args, hp=None)
+                                       clip_model=None, tokenizer=None, args=args, hp=hp)
         results[corr] = result['acc1']
     logging.info(f'Summary of Results: {results}')
     logging.info(f'Average Top-1: {np.mean(list(results.values())):.3f}')
