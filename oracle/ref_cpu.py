@@ -17,6 +17,13 @@ Pinning status (see DESIGN.md "Oracle"):
     (start index 0, skip |p|^2<=1e-3) is third-party and absent: PARITY UNPINNED
   * timm EVA02 blocks (A6) - third-party, absent: PARITY UNPINNED; restated from the structure
     recorded in SURVEY.md row A6 / `extract_attention.py:121-177`
+  * ULIP-2 PointBERT encoder (A4b) - pinned vs the reference `PointTransformer` + dvae `Group`/`Encoder` run with the
+    FPS result supplied (g8_*)
+  * OpenShape PPAT (F1) - set-abstraction layer and transformer blocks pinned vs `pointnet_util.PointNetSetAbstraction`
+    and `ppta.Transformer` (g9_*); the three glue lines that need torch_redstone (absent) are PARITY UNPINNED
+  * full-covariance DOTA (F2) - pinned, bit-exact vs the reference `dota.DOTA` class (g10_*)
+  * original cluster cache + graph refinement (F3) - pinned, bit-exact vs `update_cache` / `compute_cache_logits` /
+    `utils/math_utils.py` (g11_*)
 
 All functions take/return torch CPU tensors; `dtype` selects fp32 (reference arithmetic) or
 fp64 (used by tests as the "true value" to bound fp32 noise).
