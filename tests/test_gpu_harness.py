@@ -329,3 +329,21 @@ def test_cluster_cache_branch_of_the_harness():
     oc = O.ClusterCache(text, 2, 150.0, 0.5, 0.11)
     hits = sum(int(oc.step(feats[i:i + 1])[0].argmax()) == int(tgt[i]) for i in range(n))
     assert abs(acc['acc1'] - 100.0 * hits / n) < 1e-6
+
+
+def test_two_stream_encode_equals_single_batch():
+    """The original and augmented clouds encoded as two batches on two HIP streams give bit-identical features."""
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    sd = synthetic.uni3d_state_dict(1, trans_dim=128, embed_dim=256, depth=2, device='cuda')
+    model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    text = synthetic.text_bank(10, 256, 2)
+    xyz, rgb = synthetic.point_clouds(6, 1024, 3, device='cuda')
+    noise = torch.randn(6, 1024, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    a = TtaEngine(model, text, cfg, 2, chunk=6, device=torch.device('cuda'), two_stream_encode=True)
+    b = TtaEngine(model, text, cfg, 2, chunk=6, device=torch.device('cuda'), two_stream_encode=False)
+    fa = a.encode_chunk(xyz, rgb, noise); fb = b.encode_chunk(xyz, rgb, noise)
+    torch.cuda.synchronize()
+    assert a.two_stream_encode and not b.two_stream_encode and torch.equal(fa, fb)

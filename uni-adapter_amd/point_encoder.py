@@ -285,10 +285,12 @@ class PointcloudEncoder(nn.Module):
         self.norm = (d(sd['visual.norm.weight']), d(sd['visual.norm.bias'])) if 'visual.norm.weight' in sd else None
         self.fc_norm = (d(sd['visual.fc_norm.weight']), d(sd['visual.fc_norm.bias'])) if 'visual.fc_norm.weight' in sd else None
         self._ws = {}
+        self.ws_slot = 0          # forwards enqueued on different streams must use different workspace slots
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bc):
-        ws = self._ws.get(Bc)
+        key = (Bc, self.ws_slot)
+        ws = self._ws.get(key)
         if ws is not None:
             return ws
         G, S, Cd = self.num_group, self.group_size, self.trans_dim
@@ -304,7 +306,7 @@ class PointcloudEncoder(nn.Module):
                       hid=e(rows, Hp), hidn=e(rows, Hp))
             for i, (wc, _, _, _) in enumerate(self.sa[:-1]):
                 ws[f'sa{i}'] = e(Mp, wc.shape[0])
-            self._ws[Bc] = ws
+            self._ws[key] = ws
             return ws
         ws = dict(
             centers=e(Bc, G, 3), centers4=torch.zeros(Bc * G, 4, device=self.dev), feat=e(Mp, 8),
@@ -312,7 +314,7 @@ class PointcloudEncoder(nn.Module):
             h3=e(Mp, self.n3), tok=e(Bc * G, self.enc_dim), tokc=e(Bc * G, Cd), posh=e(Bc * G, 128),
             pos=e(Bc * G, Cd), x=e(rows, Cd), h=e(rows, Cd), qkv=e(rows, 3 * Cd), att=e(rows, Cd),
             hid=e(rows, Hp), hidn=e(rows, Hp), cls=e(Bc, Cd), cls2=e(Bc, Cd), out=e(Bc, self.embed_dim))
-        self._ws[Bc] = ws
+        self._ws[key] = ws
         return ws
 
     @torch.no_grad()
