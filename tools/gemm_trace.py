@@ -23,12 +23,12 @@ SHAPES = {  # (M, N, K) at chunk 31 (rows = 31*513)
 }
 
 
-def build():
+def build(extra=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     src = os.path.join(CSRC, 'ua_gemm_split.hip')
-    if os.path.exists(OUT) and os.path.getmtime(OUT) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, 'ua_gemm_common.h'))):
+    if not extra and os.path.exists(OUT) and os.path.getmtime(OUT) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, 'ua_gemm_common.h'))):
         return OUT
-    cmd = ['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=off', '-DUA_SPLIT_TRACE',
+    cmd = ['/opt/rocm/bin/hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=off', '-DUA_SPLIT_TRACE', *extra,
            '-I', os.path.join(ROOT, 'include'), '-shared', src, '-o', OUT]
     subprocess.run(cmd, check=True)
     return OUT
@@ -38,9 +38,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--shapes', default='qkv,proj,fc1,fc2,conv3,small')
     ap.add_argument('--build-only', action='store_true')
+    ap.add_argument('--store-only', action='store_true', help='ablation: first epilogue half = 16 plain float4 row stores (no LDS, no math)')
     ap.add_argument('--pool-only', action='store_true', help='no C stores: epilogue writes only a 64-row max-pool (store-path ablation)')
     a = ap.parse_args()
-    so = build()
+    so = build(('-DUA_EPI_STORE_ONLY',) if a.store_only else ())
     if a.build_only:
         return
     lib = C.CDLL(so)

@@ -137,15 +137,20 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
     const bool pool32 = g.pool_rows == 32;
     const float* sp = stage + lr * EP_LD + c4;
-    float* cp = g.C ? g.C + (size_t)m_first * g.ldc + nout0 : nullptr;
-    unsigned char* qp = g.Cs ? g.Cs + (size_t)m_first * g.ldcs * 4 + split_col_off(nout0) : nullptr;
+    // wave-uniform flags stay scalar: testing the per-lane pointers instead makes every `if` an exec-mask branch
+    const bool have_c = g.C != nullptr, have_s = g.Cs != nullptr;
+    float* cp = g.C + (size_t)m_first * g.ldc + nout0;
+    unsigned char* qp = g.Cs + (size_t)m_first * g.ldcs * 4 + split_col_off(nout0);
     const size_t cstep = (size_t)4 * g.ldc, qstep = (size_t)16 * g.ldcs;
+    // all 16 staged rows are requested from LDS before the first one is used (one latency instead of sixteen)
+    float4 vin[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) vin[p] = *reinterpret_cast<const float4*>(sp + p * 4 * EP_LD);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-        float4 v = *reinterpret_cast<const float4*>(sp + p * 4 * EP_LD);
+        float4 v = vin[p];
         const float4 bp = p < 8 ? ba : bb;
         v.x = v.x * as + bp.x; v.y = v.y * as + bp.y; v.z = v.z * as + bp.z; v.w = v.w * as + bp.w;
-        const bool row_ok = FULL || m_first + p * 4 < g.M;
         if (affine) { v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w; }
         if (ACT == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (ACT == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
@@ -156,14 +161,25 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
             v.x = silu(v.x) * u.x; v.y = silu(v.y) * u.y; v.z = silu(v.z) * u.z; v.w = silu(v.w) * u.w;
         }
         v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
-        if (row_ok && active) {
-            if (cp) st4(cp + p * cstep, v);
-            if (qp && (FULL || nout0 + 3 < n_out)) {                  // n_out % 4 == 0 is required with Cs
+        const bool lane_ok = (FULL || m_first + p * 4 < g.M) && active;         // FULL and not SwiGLU: constant true
+        if (FULL && !swiglu) {
+            if (have_c) *reinterpret_cast<float4*>(cp + p * cstep) = v;
+            if (have_s) {
                 f16x4 hi, lo;
                 split4(v, g.cs_scale, hi, lo);
                 *reinterpret_cast<f16x4*>(qp + p * qstep) = hi;
                 *reinterpret_cast<f16x4*>(qp + p * qstep + 64) = lo;
             }
+        } else if (lane_ok) {
+            if (have_c) st4(cp + p * cstep, v);
+            if (have_s && (FULL || nout0 + 3 < n_out)) {                  // n_out % 4 == 0 is required with Cs
+                f16x4 hi, lo;
+                split4(v, g.cs_scale, hi, lo);
+                *reinterpret_cast<f16x4*>(qp + p * qstep) = hi;
+                *reinterpret_cast<f16x4*>(qp + p * qstep + 64) = lo;
+            }
+        }
+        if (lane_ok) {
             if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
             else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
         }

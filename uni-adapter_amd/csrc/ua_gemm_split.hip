@@ -437,7 +437,17 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
         if constexpr (B16) ua::stage_64x64_b16(stage, acc, 0, lane);
         else ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
         UA_ES(0);
+#if defined(UA_SPLIT_TRACE) && defined(UA_EPI_STORE_ONLY)
+        {   // ablation (tools/gemm_trace.py --store-only): the 16 row stores of the sub-tile without LDS reads or arithmetic
+            const int lr = lane >> 4, c4 = (lane & 15) * 4;
+            float* cp = g.ep.C + (size_t)(m0 + wm * 128 + lr) * g.ep.ldc + n0 + wn * 64 + c4;
+            const float4 v = make_float4((float)lane, 1.f, 2.f, 3.f);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) *reinterpret_cast<float4*>(cp + (size_t)p * 4 * g.ep.ldc) = v;
+        }
+#else
         ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128, n0 + wn * 64);
+#endif
         UA_ES(1);
     }
     if (m0 + wm * 128 + 64 < g.M) {
