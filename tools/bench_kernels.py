@@ -156,6 +156,38 @@ def encoders():
         del models
 
 
+def caches():
+    """Per-sample cost of the two other caches (rows F2 / F3) at ModelNet40 sizes."""
+    import time
+    from uni_adapter_amd.dota import DOTA
+    from uni_adapter_amd.uni_cache import ClusterCache
+    from uni_adapter_amd import synthetic
+    print('== full-covariance DOTA and cluster cache, per sample')
+    for K, D in ((40, 512), (40, 1024)):
+        text = synthetic.text_bank(K, D, seed=1)
+        g = torch.Generator().manual_seed(2)
+        X = torch.nn.functional.normalize(text[torch.randint(0, K, (24,), generator=g)] + 0.3 * torch.randn(24, D, generator=g), dim=1).cuda()
+        Y = torch.softmax(100 * X @ text.cuda().T, 1)
+        m = DOTA({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.T.clone())
+        for i in range(4):
+            m.predict(X[i:i + 1].half()); m.fit(X[i:i + 1], Y[i:i + 1]); m.update()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(4, 24):
+            m.predict(X[i:i + 1].half()); m.fit(X[i:i + 1], Y[i:i + 1]); m.update()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+        print(f'DOTA full covariance K={K} D={D}: {dt * 1e3:6.2f} ms per sample (predict + fit + update: {2 * K * D * D * 4 / 1e6:.0f} MB of covariance traffic, '
+              f'blocked inverse + 3 Newton-Schulz steps)')
+        c = ClusterCache(text, {'shot_capacity': 30, 'beta': 150, 'threshold': 0.5, 'lambda_reg': 0.11})
+        feats = torch.nn.functional.normalize(text[torch.arange(1500) % K] + 0.35 * torch.randn(1500, D, generator=g), dim=1).cuda()
+        for i in range(1300):
+            c.step(feats[i:i + 1])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(1300, 1400):
+            c.step(feats[i:i + 1])
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
+        print(f'cluster cache K={K} D={D}: {dt * 1e3:6.2f} ms per sample at {sum(c.sizes)} prototypes (last CG iterations: {c.last_cg_iterations})')
+
+
 def replay():
     """In-order cache replay alone (ua_tta_chunk, K=40 M=8 D=1024, residual learning on): ms per sample."""
     import ctypes
@@ -179,6 +211,6 @@ def replay():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay', 'encoders']
+    which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay', 'encoders', 'caches']
     for w in which:
         globals()[w]()
