@@ -36,8 +36,8 @@ class DOTA(torch.nn.Module):
         self.c = torch.ones(K, dtype=torch.float32, device=dev)                                     # :28
         self.Sigma = (cfg['sigma'] * torch.eye(D, dtype=torch.float32, device=dev)).repeat(K, 1, 1).contiguous()   # :29
         self.overall_Sigma = torch.mean(self.Sigma, dim=0).contiguous()                             # :30
-        # pinverse of sigma*I (:31): exact on the host, one time
-        self.Lambda = torch.pinverse(self.overall_Sigma.double().cpu()).to(dev).half().contiguous()
+        # pinverse(sigma * I).half() (:31) = I / sigma, closed form (fp64 -> fp16 like the reference)
+        self.Lambda = (torch.eye(D, dtype=torch.float64, device=dev) / float(cfg['sigma'])).half().contiguous()
         self._A = torch.empty(D, D, device=dev); self._inv = torch.empty(D, D, device=dev)
         self._W = torch.empty(D, K, dtype=torch.float16, device=dev)
         self._U = torch.empty(D, D, device=dev); self._X2 = torch.empty(D, D, device=dev)
