@@ -72,6 +72,22 @@ def main():
                                      C.byref(epi), None)
         lib.ua_gemm_split_set_trace(C.c_void_p(0), C.c_void_p(0))
         ref = None
+        res = {0: [], 1: []}
+        for rep in range(8):                                 # tile-order A/B on the default schedule, interleaved
+            for order in (0, 1):
+                lib.ua_gemm_split_set_schedule(16); lib.ua_gemm_split_set_tile_order(order)
+                for _ in range(2):
+                    assert run() == 0
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run()
+                e1.record(); torch.cuda.synchronize()
+                res[order].append(e0.elapsed_time(e1) / 10 * 1e3)
+        med = {o: sorted(v)[len(v) // 2] for o, v in res.items()}
+        print(f'{name}: tile order row-major band {med[0]:.0f} us (min {min(res[0]):.0f}) | blocked 4x8 {med[1]:.0f} us (min {min(res[1]):.0f})', flush=True)
+        lib.ua_gemm_split_set_tile_order(1)
         for sched in (2, 8, 16, 2, 8, 16):                 # A/B in one process, interleaved
             lib.ua_gemm_split_set_schedule(sched)
             for _ in range(3):

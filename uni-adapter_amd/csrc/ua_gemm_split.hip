@@ -37,6 +37,7 @@ struct SplitArgs {
     EpiArgs ep;
     int tiles_n, n_tiles;
     int stagger;                                     // waves 4-7 run half a slab behind waves 0-3
+    int block_order;                                 // 2D-blocked tile walk (L2 locality)
 #ifdef UA_SPLIT_TRACE
     unsigned long long* trace;                       // [block][wave][6] cycle accumulators (tools/gemm_trace.py)
     unsigned long long* timeline;                    // [block][8] s_memrealtime (100 MHz): start, main loop end, block end, full?, 4 epilogue stamps (wave 0)
@@ -373,7 +374,22 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
         for (int x = 0; x < xcd; ++x) start += count(x);
         tile = start + ((bid - first(xcd)) >> 3);
     }
-    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    if (g.block_order && g.tiles_n >= 8 && tile < n_full) {          // (narrow outputs are already compact; measured: no gain below 8 column tiles)
+        // 2D-blocked walk of the full tiles: the ~32 workgroups an XCD runs at a time cover 4 row panels x 8 column
+        // tiles (12 operand panels per K-tile step in its L2) instead of 1-3 row panels x all column tiles (up to 24)
+        constexpr int BR = 4, BC = 8;
+        const int rows_full = g.M / SBM;
+        const int rb = tile / (BR * g.tiles_n);
+        const int h = min(BR, rows_full - rb * BR);                         // row panels in this row block
+        const int o1 = tile - rb * BR * g.tiles_n;
+        const int ncb = (g.tiles_n + BC - 1) / BC;
+        const int cb = min(o1 / (h * BC), ncb - 1);
+        const int o2 = o1 - cb * h * BC;
+        const int bc = min(BC, g.tiles_n - cb * BC);                        // column tiles in this column block
+        tm = rb * BR + o2 / bc;
+        tn = cb * BC + o2 % bc;
+    }
     const int m0 = tm * SBM, n0 = tn * SBN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
@@ -507,8 +523,10 @@ extern "C" int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, i
 }
 
 static int g_sched = -1;
+static int g_block_order = -1;
 #ifdef UA_SPLIT_TRACE
 extern "C" void ua_gemm_split_set_schedule(int v) { g_sched = v; }
+extern "C" void ua_gemm_split_set_tile_order(int v) { g_block_order = v; }
 static unsigned long long* g_trace = nullptr;
 static unsigned long long* g_timeline = nullptr;
 extern "C" void ua_gemm_split_set_trace(unsigned long long* p, unsigned long long* tl) { g_trace = p; g_timeline = tl; }
@@ -532,6 +550,8 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     static const int stagger = [] { const char* e = getenv("UA_SPLIT_STAGGER"); return e ? atoi(e) : 1; }();
     if (g_sched < 0) { const char* e = getenv("UA_SPLIT_SCHEDULE"); g_sched = e ? atoi(e) : 16; }              // 16 (default) | 8 | 2: A/B aid
     const int sched = g_sched;
+    if (g_block_order < 0) { const char* e = getenv("UA_SPLIT_TILE_ORDER"); g_block_order = e ? atoi(e) : 1; }
+    g.block_order = g_block_order;
     g.stagger = stagger;
 #ifdef UA_SPLIT_TRACE
     g.trace = g_trace; g.timeline = g_timeline;
