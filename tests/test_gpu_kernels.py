@@ -732,3 +732,20 @@ def test_cluster_cache_stream_vs_reference_fixture(ua, golden_dir):
     assert c.count.cpu()[idx].tolist() == g['final_counts'].tolist()
     with pytest.raises(NotImplementedError):
         ClusterCache(text, dict(hp, use_new_approximation=False))
+
+
+@pytest.mark.parametrize('N', [2048, 2304, 3328, 5504])
+def test_gemm_split_every_tile_is_written_once_under_the_blocked_tile_walk(ua, N):
+    """Ragged grids (row panels not a multiple of 4, 8-13-21.5 column tiles, thin last row panel): the 2D-blocked tile
+    order must stay a bijection - every output element equals the reference, nothing left at the poison value."""
+    from uni_adapter_amd.lib import GemmEpilogue
+    K = 64
+    for M in (256, 256 * 3 + 31, 256 * 5, 256 * 9 + 200, 256 * 12):
+        g = torch.Generator(device='cuda').manual_seed(M + N)
+        A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / 8
+        As, Ws = _split(ua, A), _split(ua, W, scale=256.0)
+        Cd = torch.full((M, N), 12345.0, device='cuda')
+        e = GemmEpilogue()
+        ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
+        ref = (A.double() @ W.double().T).float()
+        assert (Cd - ref).abs().max().item() < 1e-4, (M, N)
