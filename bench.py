@@ -228,6 +228,13 @@ def main():
         samples = n_global * a.steps
         log(f'[{precision}] timed region: {dt:.3f}s for {samples} samples')
         kinds = {k: prof.summary(k) for k in ('f32', 'split')}
+        if world > 1:
+            # GEMM statistics of ALL ranks (in 'owner' replay mode rank 0 may encode little or nothing)
+            t = torch.tensor([[kinds[k]['flops'], kinds[k]['ms'], kinds[k]['launches']] for k in ('f32', 'split')],
+                             device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            for i, k in enumerate(('f32', 'split')):
+                kinds[k] = dict(flops=float(t[i, 0]), ms=float(t[i, 1]), launches=int(t[i, 2]))
         dom = max(kinds, key=lambda k: kinds[k]['ms'])
         g = kinds[dom]
         tfl = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
@@ -247,7 +254,7 @@ def main():
         roof['pmc_probe'] = pmc_probe('gemm_split_kernel<16>' if dom == 'split' else 'gemm_f32_mfma_kernel')
         roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
-                     'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt, 4)})
+                     'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt / world, 4)})
         preds = out[2].clone()
         del eng, model
         torch.cuda.empty_cache()
