@@ -205,3 +205,19 @@ def test_openshape_full_depth_logits_wrapper():
     fh, z, ent, p, pred = get_logits_wrapper(types.SimpleNamespace(vlm3d='openshape'), model, pc[:1].cuda(), text.t().contiguous().cuda())
     rz = 100.0 * torch.nn.functional.normalize(ref[:1], dim=1) @ text.t()
     assert (z.cpu() - rz).abs().max().item() < 1e-3 and pred == int(rz.argmax())
+
+
+@pytest.mark.parametrize('family', ['ulip', 'openshape'])
+def test_other_encoders_are_batch_invariant_across_front_end_chunks(family):
+    """11 clouds = two mini-PointNet / set-abstraction chunks (8 + 3): every row equals the single-cloud result."""
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_ulip_from_state_dict, create_openshape_from_state_dict
+    if family == 'ulip':
+        model = create_ulip_from_state_dict(synthetic.ulip_state_dict(3, depth=2, device='cuda'), num_group=128, device='cuda', precision='split')
+    else:
+        model = create_openshape_from_state_dict(synthetic.openshape_state_dict(3, depth=2, device='cuda'), patches=128, device='cuda', precision='split')
+    pc = _clouds(11, 1024, 21).cuda()
+    full = model.encode_pc(pc)
+    for i in (0, 7, 8, 10):
+        one = model.encode_pc(pc[i:i + 1])
+        assert torch.equal(one[0], full[i]), i
