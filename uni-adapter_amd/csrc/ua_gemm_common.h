@@ -84,6 +84,9 @@ __device__ __forceinline__ void stage_64x64_b16(float* stage, const f32x4 (&acc)
 // wave-uniform (scalar) branches and all row addresses advance by pointer increments.
 template <bool FULL, int ACT>
 __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+    // the library is built with -ffp-contract=off for the element-wise cache kernels; here acc*scale + bias and the BN
+    // affine may fuse (one rounding instead of two, half the VALU instructions of the row loop)
+#pragma clang fp contract(fast)
     constexpr bool swiglu = ACT == 3;
     const int lr = lane >> 4, c4 = (lane & 15) * 4;
     const int ncol0 = ncol_base + c4;                                // input column of .x
