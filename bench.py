@@ -142,6 +142,7 @@ def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
     s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
     enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
     t_enc = t_cache = 0.0
+    finals = []
     with torch.no_grad():
         enc(torch.cat([xyz[:1], rgb[:1]], -1))     # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
@@ -151,13 +152,13 @@ def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
             f = enc(torch.cat([xyz[i:i + 1], rgb[i:i + 1]], -1))
             fa = enc(torch.cat([xyz[i:i + 1] + 0.05 * noise[i:i + 1], rgb[i:i + 1]], -1))
         b = time.perf_counter()
-        s.step(f, fa)
+        finals.append(s.step(f, fa)[2])
         t_enc += b - a; t_cache += time.perf_counter() - b
         log(f'cpu sample {i}: enc {b - a:.2f}s cache {time.perf_counter() - b:.2f}s')
     dt = time.perf_counter() - t0
     return {'value': round(n / dt, 4), 'unit': 'point-clouds/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'first {n} samples of the same synthetic stream (2 encoder forwards + cache step + residual learning each); '
-                      f'encoder {t_enc / n:.2f} s/sample, cache+residual {t_cache / n:.2f} s/sample'}
+                      f'encoder {t_enc / n:.2f} s/sample, cache+residual {t_cache / n:.2f} s/sample'}, torch.cat(finals)
 
 
 def main():
@@ -210,8 +211,12 @@ def main():
             return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
 
         log(f'[{precision}] model + stream resident; warm-up')
+        first = None
         for i in range(a.warmup):
-            step(i)
+            o = step(i)
+            if i == 0:
+                eng.synchronize()
+                first = (o[0].detach().cpu().clone(), o[2].detach().cpu().clone())     # final logits, predictions of samples 0..n-1
         prof = PE.GemmProfiler()
         fence()
         PE.PROFILER = prof
@@ -258,7 +263,7 @@ def main():
         preds = out[2].clone()
         del eng, model
         torch.cuda.empty_cache()
-        return {'value': round(samples / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'roofline': roof}, preds
+        return {'value': round(samples / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'roofline': roof, 'first': first}, preds
 
     main_mode, (res, preds) = a.precision, run_mode(a.precision)
     out = {
@@ -288,7 +293,13 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
         n = a.cpu_samples
-        out['cpu_baseline'] = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg)
+        out['cpu_baseline'], cpu_final = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg)
+        if res.get('first') is not None and a.warmup > 0 and n <= n_global:
+            # without real data the bench reports agreement with the CPU restatement on the synthetic stream
+            g_final, g_pred = res['first']
+            out['cpu_baseline']['agreement'] = {
+                'samples': n, 'predictions_identical': int((g_pred[:n].long() == cpu_final.argmax(1)).sum()),
+                'max_abs_logit_diff': round(float((g_final[:n] - cpu_final).abs().max()), 6)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
