@@ -279,6 +279,8 @@ def main():
                    'replay_overlap': bool(a.overlap),
                    'parallelism': (f'sample-sharded encoder x{world}, in-order cache replay on rank 0 (its encoder share reduced to balance), '
                                    f'1 all_gather/step' if world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'owner' else
+                                   f'sample-sharded encoder AND cache replay x{world}; 1 all_gather of sufficient-statistic deltas/step '
+                                   f'(NOT exact: E-steps see a state up to one step stale)' if world > 1 and os.environ.get('UA_REPLAY_MODE') == 'delta' else
                                    f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step' if world > 1 else
                                    'one GPU: encoder on the main stream, in-order cache replay on a second stream')},
         'roofline': res['roofline'],

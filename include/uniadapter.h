@@ -327,6 +327,25 @@ int ua_cluster_logits(const float* xT, int32_t ld, const float* keys, const floa
 int ua_add_pos(float* x, const float* pos, const float* cls_pos, int32_t Bc, int32_t G, int32_t C, void* stream);
 int ua_cls_max_concat(const float* x, float* out, int32_t Bc, int32_t G, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * "Prototype deltas" multi-GPU mode (BASELINE.json north_star: "RCCL all-gather over xGMI of per-rank
+ * prototype deltas after each chunk").  No reference counterpart - its loop is single-process (Uni_Adapter.py:368-579);
+ * the statistics are the ones its M-step carries (dota_mixture.py:196-230).  Every rank replays its own shard of a step
+ * from the common state S0 = (mu0, var0, c0), then
+ * ua_gmm_delta_pack: out = [dS1 (K*M*D) | dS2 (K*M*D) | dC (K*M)],  dS1 = c*mu - c0*mu0,  dS2 = c*var - c0*var0,  dC = c - c0
+ *   (fp64 products, stored fp32); D % 4 == 0.
+ * ua_gmm_delta_merge: deltas = W packed buffers, buffer r at deltas + r*stride (stride % 4 == 0), summed in rank order:
+ *   c = c0 + sum dC, mu = (c0*mu0 + sum dS1)/(c+1e-10), var = max((c0*var0 + sum dS2)/(c+1e-10), 1e-8), pi = c/(sum_m c + 1e-10).
+ * ua_vec_delta: out = cur - base.   ua_vec_merge: out = base + scale * sum_r deltas[r*stride + i]  (class counts: scale 1;
+ *   text residuals and their Adam moments: scale 1/W, "average of the per-rank Adam deltas").
+ * ------------------------------------------------------------------------------------------ */
+int ua_gmm_delta_pack(const float* mu, const float* var, const float* c, const float* mu0, const float* var0, const float* c0,
+                      int32_t K, int32_t M, int32_t D, float* out, void* stream);
+int ua_gmm_delta_merge(float* mu, float* var, float* pi, float* c, const float* mu0, const float* var0, const float* c0,
+                       const float* deltas, int32_t W, int64_t stride, int32_t K, int32_t M, int32_t D, void* stream);
+int ua_vec_delta(const float* cur, const float* base, int64_t n, float* out, void* stream);
+int ua_vec_merge(const float* base, const float* deltas, int32_t W, int64_t stride, int64_t n, float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -860,3 +860,97 @@ class TtaStream:
         final = fuse_logits(z, dz, self.st.c, cfg.rho, cfg.eta, batch=f.shape[0])   # :491-521
         self.i += 1
         return z, dz, final, int(pred[0])
+
+
+# ======================================================================================
+# (e)  "prototype deltas" multi-GPU mode - SURVEY section 8(e); NO reference counterpart
+# ======================================================================================
+def even_counts(n: int, world: int) -> List[int]:
+    """Contiguous, near-even blocks of an n-sample step in rank order (uni_adapter_amd/stream.py:shard_counts, rho = 0)."""
+    if world == 1:
+        return [n]
+    x0 = min(max(int(round(n / world)), 0), n)
+    rest, others = n - x0, world - 1
+    return [x0] + [rest // others + (1 if r < rest % others else 0) for r in range(others)]
+
+
+class TtaDeltaStream:
+    """W emulated ranks: each replays ITS block of a step with the sequential loop body (TtaStream.step) from the common
+    state S0, the sufficient-statistic deltas dC = c - c0, dS1 = c*mu - c0*mu0, dS2 = c*var - c0*var0 (fp64 products,
+    exchanged as `dtype`) are summed in rank order and merged:  c = c0 + sum dC, mu = (c0*mu0 + sum dS1)/(c + 1e-10),
+    var = max((c0*var0 + sum dS2)/(c + 1e-10), 1e-8), pi = c/(sum_m c + 1e-10); class counts add; text residuals and their
+    Adam moments take the AVERAGE of the per-rank changes; the Adam step count advances by the largest per-rank count.
+    E-steps inside a step see a stale state, so results differ from the sequential reference unless W*chunk = 1 - this
+    class defines the mode for the parity tests of the HIP path, it is not pinned by a reference output."""
+
+    def __init__(self, text_kd: torch.Tensor, cfg: TtaConfig, world: int, dtype=torch.float32):
+        self.s = TtaStream(text_kd, cfg, dtype)
+        self.world = int(world)
+        self.dtype = dtype
+
+    def _replica(self) -> TtaStream:
+        s, r = self.s, TtaStream.__new__(TtaStream)
+        r.cfg, r.dtype, r.text0, r.st = s.cfg, s.dtype, s.text0, s.st.clone()
+        r.res = s.res.clone()
+        r.adam = AdamState(s.adam.m.clone(), s.adam.v.clone(), s.adam.step)
+        r.i, r.last_loss = s.i, None
+        return r
+
+    def local(self, block: torch.Tensor, start: int):
+        """One rank's part of a step: replay `block` ((b,2,D), global offset `start` inside the step) from the common
+        state.  Returns (packed deltas 1-D `dtype` = [dS1 | dS2 | dC | dcc | dres | dm | dv], finals list, preds list,
+        Adam steps taken)."""
+        s, dt, f64 = self.s, self.dtype, torch.float64
+        rep = self._replica()
+        rep.i = s.i + start
+        finals, preds = [], []
+        for j in range(block.shape[0]):
+            _, _, final, pred = rep.step(block[j, 0:1], block[j, 1:2])
+            finals.append(final[0]); preds.append(pred)
+        c0, cr = s.st.c.to(f64), rep.st.c.to(f64)
+        parts = [cr[..., None] * rep.st.mu.to(f64) - c0[..., None] * s.st.mu.to(f64),
+                 cr[..., None] * rep.st.var.to(f64) - c0[..., None] * s.st.var.to(f64), cr - c0,
+                 rep.st.class_counts - s.st.class_counts, rep.res - s.res, rep.adam.m - s.adam.m, rep.adam.v - s.adam.v]
+        return torch.cat([p.to(dt).reshape(-1) for p in parts]), finals, preds, rep.adam.step - s.adam.step
+
+    def merge(self, packed, n: int, steps: int) -> None:
+        """packed: the W ranks' buffers in rank order (what the all_gather returns); sums are fp64 in rank order."""
+        s, W, dt, f64 = self.s, self.world, self.dtype, torch.float64
+        K, M, D = s.st.mu.shape
+        nS = K * M * D
+        tot = torch.zeros_like(packed[0], dtype=f64)
+        for p in packed:
+            tot += p.to(f64)
+        o = [0, nS, 2 * nS, 2 * nS + K * M, 2 * nS + K * M + K]
+        o += [o[4] + K * D, o[4] + 2 * K * D, o[4] + 3 * K * D]
+        dS1, dS2, dC, dcc, dres, dm, dv = (tot[o[i]:o[i + 1]] for i in range(7))
+        c0 = s.st.c.to(f64)
+        c = (c0 + dC.view(K, M)).to(dt)
+        den = c.to(f64)[..., None] + 1e-10
+        s.st.mu = ((c0[..., None] * s.st.mu.to(f64) + dS1.view(K, M, D)) / den).to(dt)
+        s.st.var = ((c0[..., None] * s.st.var.to(f64) + dS2.view(K, M, D)) / den).to(dt).clamp(min=1e-8)
+        s.st.c = c
+        Ck = torch.zeros(K, dtype=dt)
+        for m in range(M):
+            Ck = Ck + c[:, m]
+        s.st.pi = c / (Ck[:, None] + 1e-10)
+        s.st.class_counts = (s.st.class_counts.to(f64) + dcc).to(dt)
+        scale = float(torch.tensor(1.0 / W, dtype=torch.float32))
+        s.res = (s.res.to(f64) + scale * dres.view(K, D)).to(dt)
+        s.adam.m = (s.adam.m.to(f64) + scale * dm.view(K, D)).to(dt)
+        s.adam.v = (s.adam.v.to(f64) + scale * dv.view(K, D)).to(dt)
+        s.adam.step += steps
+        s.i += n
+        s.st.t += 2 * n
+
+    def step_chunk(self, feats: torch.Tensor):
+        """feats (n,2,D) -> (final (n,K), preds list) in stream order."""
+        n = feats.shape[0]
+        counts = even_counts(n, self.world)
+        packed, finals, preds, steps, start = [], [], [], 0, 0
+        for r in range(self.world):
+            p, f, q, st = self.local(feats[start:start + counts[r]], start)
+            packed.append(p); finals += f; preds += q; steps = max(steps, st)
+            start += counts[r]
+        self.merge(packed, n, steps)
+        return torch.stack(finals), preds

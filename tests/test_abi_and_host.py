@@ -68,6 +68,21 @@ def test_bad_arguments_return_codes_without_gpu():
         lib.call('ua_gemm_split', p16, 48, 1.0, p16, 48, 1.0, p16, 64, 64, 64, 48, None, None)
     with pytest.raises(RuntimeError, match='invalid argument'):
         lib.call('ua_gemm_split', p16, 64, 0.0, p16, 64, 1.0, p16, 64, 64, 64, 64, None, None)
+    # 'delta' multi-GPU mode: D % 4, buffer stride too short / not a multiple of 4, misaligned delta base, W < 1
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gmm_delta_pack', p16, p16, p16, p16, p16, p16, 4, 2, 6, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gmm_delta_merge', p16, p16, p16, p16, p16, p16, p16, p16, 2, 2 * 4 * 2 * 8, 4, 2, 8, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gmm_delta_merge', p16, p16, p16, p16, p16, p16, p16, p16, 2, 2 * 4 * 2 * 8 + 4 * 2 + 2, 4, 2, 8, None)
+    with pytest.raises(RuntimeError, match='aligned'):
+        lib.call('ua_gmm_delta_merge', p16, p16, p16, p16, p16, p16, p16, p16 + 4, 2, 2 * 4 * 2 * 8 + 4 * 2, 4, 2, 8, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_vec_merge', p16, p16, 0, 16, 16, 1.0, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_vec_merge', p16, p16, 2, 8, 16, 0.5, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_vec_delta', p16, None, 16, p16, None)
     e = lib.GemmEpilogue(); e.rowgroup_add = p16; e.ldg = 64; e.group_rows = 48
     with pytest.raises(RuntimeError, match='envelope'):
         lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 96, 64, 64, ctypes.byref(e), None)

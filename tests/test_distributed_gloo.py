@@ -144,3 +144,84 @@ def test_shard_counts_balance_rule():
     # the rule of stream.py: x0 = (n/W) max(0, 1 - rho (W-1))
     assert shard_counts(62, 2, rho=0.14)[0] == 27 and shard_counts(124, 4, rho=0.14)[0] == 18 and shard_counts(248, 8, rho=0.14)[0] == 1
     assert shard_counts(248, 8)[0] == 0 and shard_counts(248, 8, rho=0.2)[0] == 0
+
+
+def _worker_delta(rank, world, port, n, step, out):
+    """'delta' mode over gloo: every rank replays only its even block (oracle loop body), ONE gather_deltas per step,
+    merge in rank order."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import gather_deltas, shard_counts
+    from oracle import ref_cpu as O
+    text, feats = _delta_inputs(n)
+    d = O.TtaDeltaStream(text, O.TtaConfig(num_modes=2), world)
+    finals = []
+    for s0 in range(0, n, step):
+        nn_ = min(step, n - s0)
+        counts = shard_counts(nn_, world, 0.0)
+        start = sum(counts[:rank])
+        packed, f, _, steps = d.local(feats[s0 + start:s0 + start + counts[rank]], start)
+        res = torch.zeros(max(counts), text.shape[0])
+        if f:
+            res[:len(f)] = torch.stack(f)
+        buf = torch.cat([packed, res.reshape(-1), torch.tensor([float(steps)])])
+        g = gather_deltas(buf, world)                                 # (W, len) - the one collective of the step
+        assert g.shape == (world, buf.numel())
+        d.merge([g[r, :packed.numel()] for r in range(world)], nn_, int(g[:, -1].max()))
+        rows = g[:, packed.numel():-1].view(world, max(counts), -1)
+        finals.append(torch.cat([rows[r, :counts[r]] for r in range(world)]))
+    res = torch.cat(finals)
+    torch.save({'final': res, 'mu': d.s.st.mu, 'res': d.s.res, 'step': d.s.adam.step}, out + f'.r{rank}')
+    dist.destroy_process_group()
+
+
+def _delta_inputs(n):
+    g = torch.Generator().manual_seed(5)
+    K, D = 5, 64
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    lab = torch.randint(0, K, (n,), generator=g)
+    feats = torch.nn.functional.normalize(text[lab][:, None, :] + 0.3 * torch.randn(n, 2, D, generator=g), dim=-1)
+    return text, feats
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_delta_mode_over_gloo_equals_single_process_emulation(tmp_path, world):
+    """N>1 'delta' path: sharding (even blocks), the one all_gather of packed deltas and the rank-order merge give every
+    rank exactly what the single-process emulation of the same rule gives."""
+    from oracle import ref_cpu as O
+    n, step = 11, 5
+    text, feats = _delta_inputs(n)
+    d = O.TtaDeltaStream(text, O.TtaConfig(num_modes=2), world)
+    want = torch.cat([d.step_chunk(feats[s0:s0 + step])[0] for s0 in range(0, n, step)])
+    out = str(tmp_path / 'delta')
+    mp.spawn(_worker_delta, args=(world, _free_port(), n, step, out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(out + f'.r{r}', weights_only=True)
+        assert torch.equal(got['final'], want)
+        assert torch.equal(got['mu'], d.s.st.mu) and torch.equal(got['res'], d.s.res) and got['step'] == d.s.adam.step
+
+
+def test_delta_mode_properties():
+    """Size-independent properties of the 'delta' rule (oracle): W = 1 reproduces the sequential stream to fp32 rounding;
+    for any W the count mass grows by exactly 2 per sample (each fit adds sum(prob) = 1) and pi stays normalised; with one
+    sample per step and W = 1 nothing is stale, so predictions are the sequential ones."""
+    from oracle import ref_cpu as O
+    n = 9
+    text, feats = _delta_inputs(n)
+    seq = O.TtaStream(text, O.TtaConfig(num_modes=2))
+    want = torch.stack([seq.step(feats[i, 0:1], feats[i, 1:2])[2][0] for i in range(n)])
+    one = O.TtaDeltaStream(text, O.TtaConfig(num_modes=2), 1)
+    got = torch.cat([one.step_chunk(feats[s0:s0 + 4])[0] for s0 in range(0, n, 4)])
+    assert (got - want).abs().max().item() < 1e-3 and torch.equal(got.argmax(1), want.argmax(1))
+    assert one.s.adam.step == seq.adam.step
+    for world in (2, 4):
+        d = O.TtaDeltaStream(text, O.TtaConfig(num_modes=2), world)
+        for s0 in range(0, n, 4):
+            d.step_chunk(feats[s0:s0 + 4])
+        assert abs(d.s.st.c.sum().item() - (text.shape[0] + 2.0 * n)) < 1e-3
+        assert (d.s.st.pi.sum(1) - 1).abs().max().item() < 1e-5
+        assert abs(d.s.st.class_counts.sum().item() - 2.0 * n) < 1e-3
+        assert (d.s.st.var >= 1e-8).all() and d.s.i == n

@@ -347,3 +347,121 @@ def test_two_stream_encode_equals_single_batch():
     fa = a.encode_chunk(xyz, rgb, noise); fb = b.encode_chunk(xyz, rgb, noise)
     torch.cuda.synchronize()
     assert a.two_stream_encode and not b.two_stream_encode and torch.equal(fa, fb)
+
+
+def _delta_lockstep(text, feats, labels, world, step, M):
+    """W engines driven in lock-step in ONE process: local replay + pack on each, the stacked buffers stand in for the
+    all_gather, merge on each.  Returns (finals, preds, engines)."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    from uni_adapter_amd.stream import shard_counts
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    engs = [TtaEngine(None, text, cfg, M, res_learning=True, chunk=step, replay_mode='delta', emulated_rank=(r, world)) for r in range(world)]
+    finals, preds = [], []
+    n_all = feats.shape[0]
+    for s0 in range(0, n_all, step):
+        n = min(step, n_all - s0)
+        counts = shard_counts(n, world, 0.0)
+        tgt = labels[s0:s0 + n]
+        bufs = []
+        for r, e in enumerate(engs):
+            a = s0 + sum(counts[:r])
+            bufs.append(e.delta_local(feats[a:a + counts[r]], tgt, n).clone())
+        gathered = torch.stack(bufs)
+        outs = [e.delta_merge(gathered, n) for e in engs]
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[2], outs[0][2])
+        finals.append(outs[0][0].cpu()); preds.append(outs[0][2].cpu())
+    return torch.cat(finals), torch.cat(preds), engs
+
+
+@pytest.mark.parametrize('world,step', [(2, 4), (3, 7), (4, 3)])
+def test_delta_replay_mode_vs_oracle_emulation(golden_dir, world, step):
+    """'delta' multi-GPU mode (SURVEY section 8e "prototype deltas"; no reference counterpart, NOT exact): W ranks replay
+    their own blocks from the common state, the packed sufficient-statistic deltas are merged in rank order.  Checked
+    against the oracle's emulation of the same rule (oracle.TtaDeltaStream): predictions identical; logits within 1e-3
+    of the fp32 emulation plus that emulation's own distance to its fp64 run while the stream is calm (same three-way
+    argument as test_loop_with_residual_learning_vs_reference_golden); all replicas bit-identical after every merge;
+    total count mass conserved (each fit adds exactly sum(prob) = 1)."""
+    g = _load(golden_dir, 'g2_stream_scanobjectnn.npz')
+    text = torch.from_numpy(g['text']); M = int(g['M'])
+    n = 2 * step + 1                                            # two full steps and a ragged one
+    f_cpu = torch.stack([torch.from_numpy(g['feat'][:n]), torch.from_numpy(g['feat_aug'][:n])], 1)
+    labels = torch.from_numpy(g['labels'][:n]).int()
+    final, pred, engs = _delta_lockstep(text, f_cpu.cuda(), labels, world, step, M)
+    o32 = O.TtaDeltaStream(text, O.TtaConfig(num_modes=M), world)
+    o64 = O.TtaDeltaStream(text, O.TtaConfig(num_modes=M), world, dtype=torch.float64)
+    r32, r64, p32 = [], [], []
+    for s0 in range(0, n, step):
+        a, p = o32.step_chunk(f_cpu[s0:s0 + step]); r32.append(a); p32 += p
+        r64.append(o64.step_chunk(f_cpu[s0:s0 + step].double())[0])
+    r32, r64 = torch.cat(r32).double().numpy(), torch.cat(r64).numpy()
+    final = final.double().numpy()
+    assert np.array_equal(pred.numpy(), np.array(p32)) and np.array_equal(pred.numpy(), r64.argmax(1))
+    e_hip, e_ref, e_truth = np.abs(final - r32).max(1), np.abs(r32 - r64).max(1), np.abs(final - r64).max(1)
+    print(world, 'HIP vs fp32 emulation :', np.round(e_hip, 5).tolist())
+    print(world, 'fp32 vs fp64 emulation:', np.round(e_ref, 5).tolist())
+    events = np.maximum(e_ref, e_truth) >= 0.1
+    first_event = int(np.argmax(events)) if events.any() else n
+    assert first_event >= min(5, n), first_event
+    pre = slice(0, first_event)
+    noise = np.maximum(np.maximum.accumulate(e_ref), 1e-3)
+    assert (e_hip[:3] <= 1e-3).all()
+    assert (e_hip[pre] <= 1e-3 + 2 * noise[pre]).all() and (e_truth[pre] <= 3 * noise[pre]).all()
+    # replicas identical; accuracy identical; mass conserved
+    e0 = engs[0]
+    for e in engs[1:]:
+        for a, b in ((e.mode_dota_model.mu, e0.mode_dota_model.mu), (e.mode_dota_model.var, e0.mode_dota_model.var),
+                     (e.mode_dota_model.pi, e0.mode_dota_model.pi), (e.residuals.res, e0.residuals.res), (e.residuals.e, e0.residuals.e)):
+            assert torch.equal(a, b)
+        assert e.accuracy() == e0.accuracy() and e.residuals.step == e0.residuals.step == o32.s.adam.step
+    K = text.shape[0]
+    assert abs(e0.mode_dota_model.c.sum().item() - (K + 2.0 * n)) < 1e-2
+    assert abs(e0.accuracy()['acc1'] - 100.0 * float((pred.numpy() == g['labels'][:n]).mean())) < 1e-9
+    # the merged state itself against the fp32 emulation (c exactly tracks; mu to fp32 rounding of the same formula)
+    assert (e0.mode_dota_model.c.cpu() - o32.s.st.c).abs().max().item() < 1e-4
+    if first_event == n:
+        assert (e0.mode_dota_model.mu.cpu() - o32.s.st.mu).abs().max().item() < 1e-4
+
+
+def _delta_mode_worker(rank, world, port, out):
+    """One rank of a 2-process job sharing cuda:0 (gloo): TtaEngine.process_chunk in 'delta' replay mode."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), UA_REPLAY_MODE='delta')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    finals, acc = _run_small_stream(TtaEngine, create_uni3d_from_state_dict, synthetic)
+    torch.save({'finals': finals.cpu(), 'acc': acc}, out + f'.r{rank}')
+    dist.destroy_process_group()
+
+
+def test_delta_replay_mode_two_processes_match_lockstep(tmp_path):
+    """The real exchange path (process_chunk -> all_gather of the packed deltas, 2 ranks sharing cuda:0 over gloo) gives
+    every rank the results of the lock-step emulation on the same encoder features, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    K, D, n, chunk = 10, 256, 10, 5
+    sd = synthetic.uni3d_state_dict(1, trans_dim=128, embed_dim=D, depth=1, device='cuda')
+    model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    text = synthetic.text_bank(K, D, 2)
+    xyz, rgb = synthetic.point_clouds(n, 1024, 3, device='cuda')
+    noise = torch.randn(n, 1024, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    feats = torch.stack([model.encode_pc(torch.cat((xyz, rgb), -1)), model.encode_pc(torch.cat((xyz + 0.05 * noise, rgb), -1))], 1)
+    labels = (torch.arange(n) % K).int()
+    want, _, engs = _delta_lockstep(text, feats, labels, 2, chunk, 2)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'delta.pt')
+    mp.spawn(_delta_mode_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(out + f'.r{r}', weights_only=True)
+        assert torch.equal(got['finals'], want)
+        assert got['acc'] == engs[0].accuracy()

@@ -18,7 +18,7 @@ def main():
     ap.add_argument('--priority', type=int, default=0)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--chunk', type=int, default=31)
-    ap.add_argument('--mode', default='replicated', choices=['replicated', 'owner'])
+    ap.add_argument('--mode', default='replicated', choices=['replicated', 'owner', 'delta'])
     ap.add_argument('--rho', type=float, default=None)
     a = ap.parse_args()
     dev = torch.device('cuda')
@@ -63,6 +63,30 @@ def main():
             step = max(t[3] for t in times)
             print(f'W={W} owner mode (rho {rho}): ' + '; '.join(f'{r}: {ne} encoded + {nr} replayed = {t * 1e3:.1f} ms' for r, ne, nr, t in times) +
                   f' -> {n * W / step:8.1f} point-clouds/s whole job ({n * W / step / W:6.1f} per GPU)', flush=True)
+        return
+    if a.mode == 'delta':
+        # one rank of a W-rank 'delta' job: encode + replay its own n samples, pack, merge W buffers (stand-ins for the
+        # all_gather result: this rank's buffer W times - the copy costs what receiving them would write; wire time excluded)
+        for W in [int(w) for w in a.world.split(',')]:
+            eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 8, res_learning=True, chunk=n * W, device=dev,
+                            replay_mode='delta', emulated_rank=(0, max(W, 2)), overlap=True)
+            Wm = eng.world
+            total = a.steps + 2
+            xyz, rgb = synthetic.point_clouds(n * total, 1024, seed=42, device=dev)
+            noise = torch.randn(xyz.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+            for it in range(total):
+                if it == 2:
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                s_ = slice(it * n, (it + 1) * n)
+                rep = lambda t: t[s_].repeat(Wm, 1, 1)                     # rank 0 takes the first n of the n*W-sample step
+                feats = eng.encode_chunk(rep(xyz), rep(rgb), rep(noise))
+                eng.delta_step(feats, None, n * Wm, exchange=lambda b: b[None].repeat(Wm, 1))
+            buf = eng._delta['buf']
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.steps
+            print(f'W={W} delta mode: {dt * 1e3:7.1f} ms/step (merge of {Wm} buffers of {buf.numel() * 4 / 1e6:.2f} MB) -> '
+                  f'{n * W / dt:8.1f} point-clouds/s whole job ({n / dt:6.1f} per GPU)', flush=True)
+            del eng
         return
     for W in [int(w) for w in a.world.split(',')]:
         eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 8, res_learning=True, chunk=n * W, device=dev)

@@ -23,8 +23,8 @@ import torch.nn.functional as F
 
 from . import lib
 from .dota_mixture import DOTA_mix
-from .stream import (REPLAY_COST_RATIO, broadcast_from_owner, gather_feature_blocks, gather_features, shard_block,
-                     shard_indices)
+from .stream import (REPLAY_COST_RATIO, broadcast_from_owner, gather_deltas, gather_feature_blocks, gather_features, shard_block,
+                     shard_counts, shard_indices)
 
 LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
 NOISE_STD = 0.05             # Uni_Adapter.py:420
@@ -118,7 +118,7 @@ class TtaEngine:
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
                  log_alignment_every=0, dist_group=None, composite=True, overlap=False, replay_mode=None,
-                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False):
+                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False, emulated_rank=None):
         self.model = model
         self.composite = bool(composite) and not log_alignment_every
         # overlap=True: the in-order cache replay of chunk c runs on a second HIP stream while the
@@ -147,13 +147,23 @@ class TtaEngine:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(dist_group)
             self.rank = torch.distributed.get_rank(dist_group)
+        if emulated_rank is not None:
+            # (rank, world): act as one rank of a W-rank job without a process group - the caller moves the
+            # buffers between engines itself (lock-step tests of the 'delta' mode, tools/emulate_scaling.py)
+            self.rank, self.world = int(emulated_rank[0]), int(emulated_rank[1])
         # where the sequential cache replay runs when W > 1 (stream.py): 'owner' = rank 0 only, with a
         # smaller encoder share for rank 0; 'replicated' = every rank replays everything
         self.replay_mode = replay_mode or os.environ.get('UA_REPLAY_MODE', 'owner')
-        if self.replay_mode not in ('owner', 'replicated'):
-            raise ValueError(f"replay_mode must be 'owner' or 'replicated', got {self.replay_mode!r}")
+        if self.replay_mode not in ('owner', 'replicated', 'delta'):
+            raise ValueError(f"replay_mode must be 'owner', 'replicated' or 'delta', got {self.replay_mode!r}")
+        # 'delta' (SURVEY section 8e "prototype deltas", NOT exact): every rank replays only its own block from the common
+        # state and one all_gather of sufficient-statistic deltas merges the W replicas after each step
+        self.delta_mode = self.replay_mode == 'delta' and self.world > 1
+        if self.delta_mode and not self.composite:
+            raise ValueError("replay_mode='delta' needs the composite replay (log_alignment_every=0)")
         self.replay_cost_ratio = float(replay_cost_ratio)
-        self.replays = self.world == 1 or self.replay_mode == 'replicated' or self.rank == 0
+        self.replays = self.world == 1 or self.replay_mode in ('replicated', 'delta') or self.rank == 0
+        self._delta = None
         K, D, M, dev = self.K, self.D, self.M, self.dev
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
         self.fh, self.fa = e(1, D), e(1, D)
@@ -189,7 +199,10 @@ class TtaEngine:
         features (n,2,D): [:,0] original, [:,1] augmented cloud."""
         n = pc.shape[0]
         owner_mode = self.world > 1 and self.replay_mode == 'owner'
-        mine = shard_block(n, self.rank, self.world, self.replay_cost_ratio) if owner_mode else shard_indices(n, self.rank, self.world)
+        if self.delta_mode:
+            mine = shard_block(n, self.rank, self.world, 0.0)
+        else:
+            mine = shard_block(n, self.rank, self.world, self.replay_cost_ratio) if owner_mode else shard_indices(n, self.rank, self.world)
         D = self.D
         if len(mine):
             p, c, z = pc[mine], rgb[mine], noise[mine]
@@ -210,6 +223,8 @@ class TtaEngine:
                 local = self.model.encode_pc(clouds.view(-1, clouds.shape[2], 6)).view(len(mine), 2, D)
         else:
             local = torch.zeros(0, 2, D, device=self.dev)
+        if self.delta_mode:
+            return local                          # features stay on the rank; the exchange is delta_exchange()
         # one exchange per chunk (RCCL all_gather over xGMI); a no-op at world 1
         if owner_mode:
             return gather_feature_blocks(local, n, self.rank, self.world, self.group, self.replay_cost_ratio)
@@ -271,6 +286,8 @@ class TtaEngine:
         else:
             noise = noise.to(self.dev, torch.float32)
         feats = self.encode_chunk(pc, rgb, noise)
+        if self.delta_mode:
+            return self.delta_step(feats, target, n)
         final = torch.empty(n, self.K, device=self.dev)
         ranks = torch.full((n,), -1, device=self.dev, dtype=torch.int32)
         preds = torch.empty(n, device=self.dev, dtype=torch.int32)
@@ -311,6 +328,113 @@ class TtaEngine:
         if tgt is not None:                                                                  # utils/utils.py:154-167
             self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
             self.count += n
+        return final, ranks, preds
+
+    # -- 'delta' replay mode: local replay + pack, exchange, merge (three steps so that W ranks can also be driven in
+    #    lock-step from one process: tests/test_gpu_harness.py, tools/emulate_scaling.py) ---------------------------
+    def _delta_buffers(self, per):
+        K, M, D = self.K, self.M, self.D
+        nS = K * M * D
+        o = {'S1': 0, 'S2': nS, 'C': 2 * nS, 'cc': 2 * nS + K * M}
+        o['res'] = o['cc'] + K
+        o['m'], o['v'] = o['res'] + K * D, o['res'] + 2 * K * D
+        o['out'] = o['res'] + 3 * K * D                      # per x (K final logits | rank | pred) of this rank's block
+        stride = (o['out'] + per * (K + 2) + 3) // 4 * 4
+        d = self._delta
+        if d is None or d['stride'] != stride:
+            mdl, r = self.mode_dota_model, self.residuals
+            d = {'stride': stride, 'off': o, 'per': per, 'buf': torch.zeros(stride, device=self.dev),
+                 's0': {k: torch.empty_like(t) for k, t in (('mu', mdl.mu), ('var', mdl.var), ('c', mdl.c), ('cc', mdl.class_counts))}}
+            if r is not None:
+                d['s0'].update(res=torch.empty_like(r.res), m=torch.empty_like(r.m), v=torch.empty_like(r.v))
+            self._delta = d
+        return d
+
+    def delta_local(self, feats, target, n):
+        """Replay this rank's block of an n-sample step from the common state and pack the deltas.  feats: (mine,2,D)
+        features of the block; target: (n,) labels of the WHOLE step or None.  Returns the packed fp32 buffer."""
+        import ctypes
+        K, M, D = self.K, self.M, self.D
+        counts = shard_counts(n, self.world, 0.0)
+        start, mine, per = sum(counts[:self.rank]), counts[self.rank], max(counts)
+        d = self._delta_buffers(per)
+        o, buf, s0 = d['off'], d['buf'], d['s0']
+        d['targets'] = target is not None
+        mdl, r = self.mode_dota_model, self.residuals
+        st = lib.stream_ptr()
+        live = {'mu': mdl.mu, 'var': mdl.var, 'c': mdl.c, 'cc': mdl.class_counts}
+        if r is not None:
+            live.update(res=r.res, m=r.m, v=r.v)
+        for k, t in live.items():
+            s0[k].copy_(t)                                                   # S0 (device-to-device)
+        res_out = buf[o['out']:o['out'] + per * (K + 2)]
+        res_out.zero_()
+        if mine:
+            final = torch.empty(mine, K, device=self.dev)
+            ranks = torch.full((mine,), -1, device=self.dev, dtype=torch.int32)
+            preds = torch.empty(mine, device=self.dev, dtype=torch.int32)
+            tgt = target.to(self.dev, torch.int32)[start:start + mine].contiguous() if target is not None else None
+            feats = feats.contiguous()
+            lib.call('ua_tta_chunk', ctypes.byref(self._state), lib.ptr(feats), lib.ptr(tgt, torch.int32) if tgt is not None else None,
+                     mine, self.i + start, r.step if r is not None else 0, lib.ptr(final),
+                     lib.ptr(ranks, torch.int32) if tgt is not None else None, lib.ptr(preds, torch.int32), st)
+            out = res_out.view(per, K + 2)
+            out[:mine, :K] = final
+            out[:mine, K] = ranks.float()
+            out[:mine, K + 1] = preds.float()
+        lib.call('ua_gmm_delta_pack', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(mdl.c), lib.ptr(s0['mu']), lib.ptr(s0['var']),
+                 lib.ptr(s0['c']), K, M, D, lib.ptr(buf), st)
+        lib.call('ua_vec_delta', lib.ptr(mdl.class_counts), lib.ptr(s0['cc']), K, buf.data_ptr() + 4 * o['cc'], st)
+        if r is not None:
+            for key, t in (('res', r.res), ('m', r.m), ('v', r.v)):
+                lib.call('ua_vec_delta', lib.ptr(t), lib.ptr(s0[key]), K * D, buf.data_ptr() + 4 * o[key], st)
+        return buf
+
+    def delta_step(self, feats, target, n, exchange=None):
+        """Local replay + pack, the one collective, merge - on the replay stream when overlap=True, so that the caller's
+        stream already encodes the next step meanwhile (results complete after `synchronize()`, as in the exact modes)."""
+        main = torch.cuda.current_stream()
+        rs = self.replay_stream if self.overlap else main
+        if self.overlap:
+            rs.wait_stream(main)
+            feats.record_stream(rs)
+        with torch.cuda.stream(rs):
+            buf = self.delta_local(feats, target, n)
+            return self.delta_merge((exchange or self.delta_exchange)(buf), n)
+
+    def delta_exchange(self, buf):
+        """ONE collective per step: all_gather of the packed deltas (RCCL over xGMI).  Returns (W, stride)."""
+        return gather_deltas(buf, self.world, self.group)
+
+    def delta_merge(self, gathered, n):
+        """State <- S0 + the W ranks' deltas (rank order); returns the step's (final (n,K), ranks, preds) in stream order."""
+        K, M, D, W = self.K, self.M, self.D, self.world
+        d = self._delta
+        o, s0, stride, per = d['off'], d['s0'], d['stride'], d['per']
+        gathered = gathered.contiguous()
+        assert gathered.shape == (W, stride)
+        mdl, r = self.mode_dota_model, self.residuals
+        st = lib.stream_ptr()
+        g = gathered.data_ptr()
+        lib.call('ua_gmm_delta_merge', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(mdl.pi), lib.ptr(mdl.c), lib.ptr(s0['mu']),
+                 lib.ptr(s0['var']), lib.ptr(s0['c']), g, W, stride, K, M, D, st)
+        lib.call('ua_vec_merge', lib.ptr(s0['cc']), g + 4 * o['cc'], W, stride, K, 1.0, lib.ptr(mdl.class_counts), st)
+        counts = shard_counts(n, W, 0.0)
+        if r is not None:
+            for key, t in (('res', r.res), ('m', r.m), ('v', r.v)):
+                lib.call('ua_vec_merge', lib.ptr(s0[key]), g + 4 * o[key], W, stride, K * D, 1.0 / W, lib.ptr(t), st)
+            lib.call('ua_text_normalize', lib.ptr(r.text0), lib.ptr(r.res), K, D, 0.0, lib.ptr(r.e), lib.ptr(r.norm), st)
+            starts = [sum(counts[:q]) for q in range(W)]
+            r.step += max(RES_STEPS * (counts[q] - (1 if self.i + starts[q] == 0 and counts[q] else 0)) for q in range(W))
+        out = gathered[:, o['out']:o['out'] + per * (K + 2)].view(W, per, K + 2)
+        rows = torch.cat([out[q, :counts[q]] for q in range(W)], 0)                       # stream order
+        final, ranks, preds = rows[:, :K].contiguous(), rows[:, K].to(torch.int32), rows[:, K + 1].to(torch.int32)
+        if d['targets']:
+            # every rank holds every rank's results, so the accuracy counters need no final all_reduce (Uni_Adapter.py:582)
+            self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
+            self.count += n
+        self.i += n
+        mdl.t += 2 * n
         return final, ranks, preds
 
     # -- checkpoint / resume of the adaptation state (absent in the reference; SURVEY section 8 row F4) --

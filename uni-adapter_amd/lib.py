@@ -67,6 +67,10 @@ SIGNATURES = {
     'ua_cluster_logits': [_p, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     'ua_dota_fit': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p],
     'ua_spd_inverse_small': [_p, _i64, _i32, _p, _i64, _p],
+    'ua_gmm_delta_pack': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p],
+    'ua_gmm_delta_merge': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i32, _p],
+    'ua_vec_delta': [_p, _p, _i64, _p, _p],
+    'ua_vec_merge': [_p, _p, _i32, _i64, _i64, _f, _p, _p],
     'ua_to_half': [_p, _p, _i64, _p],
     'ua_dota_predict': [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     'ua_fps': [_p, _i32, _i32, _i32, _i32, _f, _p, _p, _p],

@@ -18,6 +18,12 @@ Two ways to place the sequential part:
     finish a step together (W = 8: rank 0 encodes nothing and replays 248 samples in 74 ms while seven
     ranks encode 35-36 samples each).  Results live on rank 0; accuracies are broadcast at the end.
 Both give results identical to the single-process stream.
+  * 'delta' (opt-in, NOT exact; the north star's "all-gather of per-rank prototype deltas after each chunk"): every rank
+    replays only its own even block of the step from the common state S0 and ONE all_gather of the packed
+    sufficient-statistic deltas (dC, dS1 = d(c*mu), dS2 = d(c*var), class counts, text residuals + Adam moments;
+    (2KMD + KM + K + 3KD)*4 B per rank, 3.1 MB at K=40 M=8 D=1024) merges the W replicas.  No serial part is left, so
+    it scales like the encoder, but E-steps inside a step see a state that is up to one step stale: results differ from
+    the sequential reference and are checked against the oracle's emulation of the same rule, never used for the parity claim.
 
 Device-agnostic on purpose (no HIP calls), so the N>1 logic is covered by world_size-2 gloo tests.
 """
@@ -66,6 +72,15 @@ def _all_gather(pad, world, group):
     parts = [torch.empty_like(pad) for _ in range(world)]
     torch.distributed.all_gather(parts, pad, group=group)       # RCCL over xGMI on a multi-GPU node
     return parts
+
+
+def gather_deltas(buf, world, group=None):
+    """'delta' mode (SURVEY section 8e "prototype deltas"): the ONE collective of a step - all_gather of every rank's packed
+    sufficient-statistic deltas (1-D fp32, same length on all ranks).  Returns (world, len), row r = rank r's buffer, identical
+    on every rank; the merge kernel sums the rows in rank order, so the result does not depend on the collective's algorithm."""
+    if world == 1:
+        return buf[None]
+    return torch.stack(_all_gather(buf, world, group), 0)
 
 
 def broadcast_from_owner(t, group=None):
