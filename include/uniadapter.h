@@ -346,6 +346,18 @@ int ua_gmm_delta_merge(float* mu, float* var, float* pi, float* c, const float* 
 int ua_vec_delta(const float* cur, const float* base, int64_t n, float* out, void* stream);
 int ua_vec_merge(const float* base, const float* deltas, int32_t W, int64_t stride, int64_t n, float scale, float* out, void* stream);
 
+/* Class-sharded exact replay for large K ("rank r owns classes [rK/W,(r+1)K/W) ... exchange = all_gather of
+ * K/W scores per sample + the sum of c").  Every formula of dota_mixture.py:162-258 is independent per class, so a rank runs
+ * ua_gmm_step_fused on its slice of the state through offset pointers; the cross-class couplings are the softmax over K
+ * (clip logits: computed on every rank) and mean(c) at Uni_Adapter.py:491.  per = ceil(K/W) classes per rank.
+ * ua_class_shard_pack: out (per+2 floats) = [this rank's K_local <= per scores, zero padded | fp64 sum of its c slice as a
+ *   (hi, lo) float pair].
+ * ua_fuse_logits_sharded: ua_fuse_logits from the W gathered buffers (rank order); dota_out (K) optional.               */
+int ua_class_shard_pack(const float* scores, const float* c, int32_t K_local, int32_t M, int32_t per, float* out, void* stream);
+int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t per, int32_t K, int32_t M,
+                           float rho, float eta, int32_t batch, const int32_t* target, float* final_logits, int32_t* rank,
+                           int32_t* pred, float* dota_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,11 @@ def test_bad_arguments_return_codes_without_gpu():
         lib.call('ua_vec_merge', p16, p16, 2, 8, 16, 0.5, p16, None)
     with pytest.raises(RuntimeError, match='invalid argument'):
         lib.call('ua_vec_delta', p16, None, 16, p16, None)
+    # class-sharded replay: more local classes than the per-rank share; W * per < K
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_class_shard_pack', p16, p16, 5, 2, 4, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_fuse_logits_sharded', p16, p16, 2, 4, 9, 2, 0.02, 0.1, 1, None, p16, None, None, None, None)
     e = lib.GemmEpilogue(); e.rowgroup_add = p16; e.ldg = 64; e.group_rows = 48
     with pytest.raises(RuntimeError, match='envelope'):
         lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 96, 64, 64, ctypes.byref(e), None)

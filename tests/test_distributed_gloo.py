@@ -225,3 +225,57 @@ def test_delta_mode_properties():
         assert (d.s.st.pi.sum(1) - 1).abs().max().item() < 1e-5
         assert abs(d.s.st.class_counts.sum().item() - 2.0 * n) < 1e-3
         assert (d.s.st.var >= 1e-8).all() and d.s.i == n
+
+
+def _worker_class(rank, world, port, n, out):
+    """'class' mode over gloo: each rank keeps classes [r*per,(r+1)*per) of the oracle state; per sample one gather of
+    (score slice | partial sum of c)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import gather_deltas
+    from oracle import ref_cpu as O
+    text, feats = _delta_inputs(n)
+    K, M = text.shape[0], 2
+    per = -(-K // world)
+    k0 = min(rank * per, K); k1 = min(k0 + per, K)
+    full = O.gmm_init(text, M, 1e-4, 1e-4)
+    st = O.GmmState(full.mu[k0:k1].clone(), full.var[k0:k1].clone(), full.pi[k0:k1].clone(), full.c[k0:k1].clone(),
+                    full.class_counts[k0:k1].clone(), full.epsilon)
+    finals = []
+    for j in range(n):
+        f, z, ent, prob, pred = O.clip_logits(feats[j, 0:1], text)                 # all K, on every rank
+        fa = O.clip_logits(feats[j, 1:2], text)[0]
+        fa = fa / fa.norm(dim=-1, keepdim=True)
+        buf = torch.zeros(per + 1, dtype=torch.float64)
+        if k1 > k0:
+            buf[:k1 - k0] = O.gmm_predict(st, f.mean(0)[None].half())[0].double()
+            O.gmm_fit(st, f, prob[:, k0:k1]); O.gmm_fit(st, fa, prob[:, k0:k1])
+            buf[per] = st.c.double().sum()
+        g = gather_deltas(buf, world)                                              # the per-sample collective
+        dz = torch.cat([g[r, :per] for r in range(world)])[:K].float()[None]
+        cmean = (g[:, per].sum() / (K * M)).float()
+        finals.append(O.fuse_logits(z, dz, cmean, 0.02, 0.1))
+    torch.save({'final': torch.cat(finals), 'mu': st.mu, 'k': (k0, k1)}, out + f'.r{rank}')
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_class_sharded_replay_over_gloo_equals_single_process(tmp_path, world):
+    """N>1 'class' path: the cache step is independent per class, so rank-local slices + one small gather per sample
+    reproduce the single-process stream (K = 5 is not a multiple of W)."""
+    from oracle import ref_cpu as O
+    n = 9
+    text, feats = _delta_inputs(n)
+    s = O.TtaStream(text, O.TtaConfig(num_modes=2, res_learning=False))
+    want = torch.cat([s.step(feats[j, 0:1], feats[j, 1:2])[2] for j in range(n)])
+    out = str(tmp_path / 'class')
+    mp.spawn(_worker_class, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(out + f'.r{r}', weights_only=True)
+        np.testing.assert_allclose(got['final'].numpy(), want.numpy(), rtol=0, atol=1e-5)
+        assert torch.equal(got['final'].argmax(1), want.argmax(1))
+        k0, k1 = got['k']
+        assert torch.equal(got['mu'], s.st.mu[k0:k1])

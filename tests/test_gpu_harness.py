@@ -465,3 +465,86 @@ def test_delta_replay_mode_two_processes_match_lockstep(tmp_path):
         got = torch.load(out + f'.r{r}', weights_only=True)
         assert torch.equal(got['finals'], want)
         assert got['acc'] == engs[0].accuracy()
+
+
+@pytest.mark.parametrize('name,world', [('scanobjectnn', 4), ('scanobjectnn', 16), ('modelnet40', 8), ('shapenet55', 3)])
+def test_class_sharded_replay_is_bit_identical_to_one_gpu(golden_dir, name, world):
+    """'class' replay mode (exact mode for large K): rank r holds classes [r*per,(r+1)*per) of the state,
+    per sample one (per+2)-float buffer per rank is exchanged.  W engines driven in lock-step in one process (the stacked
+    buffers stand in for the all_gather) against ONE engine holding everything: final logits, predictions, accuracy and
+    every rank's slice of the state are bit-identical (K not a multiple of W, ranks with no class at all included)."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    text = torch.from_numpy(g['text']); M = int(g['M']); K = text.shape[0]
+    n = min(12, g['feat'].shape[0])
+    feats = torch.stack([torch.from_numpy(g['feat'][:n]), torch.from_numpy(g['feat_aug'][:n])], 1).cuda()
+    tgt = torch.from_numpy(g['labels'][:n]).int().cuda()
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    one = TtaEngine(FeatureFeeder(feats), text, cfg, M, res_learning=False, chunk=n)
+    want = one.process_chunk(torch.zeros(n, 8, 3), torch.ones(n, 8, 3), tgt.cpu())
+    engs = [TtaEngine(None, text, cfg, M, res_learning=False, chunk=n, replay_mode='class', emulated_rank=(r, world)) for r in range(world)]
+    final = torch.empty(world, n, K, device='cuda'); ranks = torch.empty(world, n, dtype=torch.int32, device='cuda')
+    preds = torch.empty(world, n, dtype=torch.int32, device='cuda')
+    for j in range(n):
+        gathered = torch.stack([e.class_local(feats[j, 0:1], feats[j, 1:2]).clone() for e in engs])
+        for r, e in enumerate(engs):
+            e.class_fuse(gathered, tgt[j:j + 1], final[r, j:j + 1], ranks[r, j:j + 1], preds[r, j:j + 1])
+    torch.cuda.synchronize()
+    for r, e in enumerate(engs):
+        assert torch.equal(final[r], want[0]) and torch.equal(ranks[r], want[1]) and torch.equal(preds[r], want[2]), r
+        k0, k1 = e.class_k0, e.class_k1
+        for a, b in ((e.mode_dota_model.mu, one.mode_dota_model.mu), (e.mode_dota_model.var, one.mode_dota_model.var),
+                     (e.mode_dota_model.pi, one.mode_dota_model.pi), (e.mode_dota_model.c, one.mode_dota_model.c),
+                     (e.mode_dota_model.class_counts, one.mode_dota_model.class_counts)):
+            assert torch.equal(a[k0:k1], b[k0:k1]), r
+    assert sum(e.class_k1 - e.class_k0 for e in engs) == K
+    with pytest.raises(ValueError, match='residual learning'):
+        TtaEngine(None, text, cfg, M, res_learning=True, replay_mode='class', emulated_rank=(0, 2))
+
+
+def _class_mode_worker(rank, world, port, out):
+    """One rank of a 2-process job sharing cuda:0 (gloo): TtaEngine.process_chunk in 'class' replay mode."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), UA_REPLAY_MODE='class')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import uni_adapter_amd  # noqa: F401
+    finals, acc = _run_small_stream_no_res()
+    torch.save({'finals': finals.cpu(), 'acc': acc}, out + f'.r{rank}')
+    dist.destroy_process_group()
+
+
+def _run_small_stream_no_res():
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    K, D, n, chunk = 11, 256, 10, 5
+    sd = synthetic.uni3d_state_dict(1, trans_dim=128, embed_dim=D, depth=1, device='cuda')
+    model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    text = synthetic.text_bank(K, D, 2)
+    xyz, rgb = synthetic.point_clouds(n, 1024, 3, device='cuda')
+    noise = torch.randn(n, 1024, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    tgt = torch.arange(n, device='cuda') % K
+    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 4, res_learning=False, chunk=chunk,
+                    device=torch.device('cuda'), overlap=True)
+    outs = [eng.process_chunk(xyz[c0:c0 + chunk], rgb[c0:c0 + chunk], tgt[c0:c0 + chunk], noise[c0:c0 + chunk])[0] for c0 in range(0, n, chunk)]
+    eng.synchronize()
+    return torch.cat(outs), eng.accuracy()
+
+
+def test_class_sharded_replay_two_processes(tmp_path):
+    """The real path (sample-sharded encoder, all_gather of features per chunk, all_gather of score slices per sample,
+    replay overlapped on the second stream) with 2 ranks sharing cuda:0 equals the single-process stream bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    ref, ref_acc = _run_small_stream_no_res()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'class.pt')
+    mp.spawn(_class_mode_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(out + f'.r{r}', weights_only=True)
+        assert torch.equal(got['finals'], ref.cpu()) and got['acc'] == ref_acc

@@ -119,6 +119,26 @@ def test_gmm_fit_gamma_zero_is_identity_and_errors(ua):
         ua.call('ua_gmm_fit', None, ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(x), ua.ptr(z), 1, 6, 4, 256, 1e-4, ua.stream_ptr())
 
 
+def test_predict_is_invariant_to_mode_permutation(ua):
+    """SURVEY section 8c property: relabelling the M modes of every class changes nothing but the order of the terms of
+    the logsumexp over modes; the per-mode joint log-probabilities are permuted exactly."""
+    K, M, D, B = 7, 8, 1024, 5
+    text, st, g = _stream_state(K, M, D, 12, 11)
+    x = dev(torch.nn.functional.normalize(text[:B] + 0.05 * torch.randn(B, D, generator=g), dim=1))
+    perm = torch.stack([torch.randperm(M, generator=g) for _ in range(K)])                  # a different permutation per class
+    idx = perm[:, :, None].expand(K, M, D)
+    outs = []
+    for mu, var, pi in ((st.mu, st.var, st.pi), (st.mu.gather(1, idx), st.var.gather(1, idx), st.pi.gather(1, perm))):
+        scores, joint = torch.empty(B, K, device='cuda'), torch.empty(B, K, M, device='cuda')
+        ua.call('ua_gmm_loglik', ua.ptr(dev(mu)), ua.ptr(dev(var)), ua.ptr(dev(pi)), ua.ptr(x), B, K, M, D, 1e-4, ua.ptr(scores),
+                ua.ptr(joint), None, ua.stream_ptr())
+        outs.append((scores.cpu(), joint.cpu()))
+    assert torch.equal(outs[1][1], outs[0][1].gather(2, perm[None].expand(B, K, M)))         # joint: exact permutation
+    assert (outs[1][0] - outs[0][0]).abs().max().item() <= 4 * torch.finfo(torch.float32).eps * outs[0][0].abs().max().item()
+    ref = O.gmm_predict(st, x.cpu())
+    assert (outs[1][0] - ref).abs().max().item() <= 2e-3 + 1e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('name', ['modelnet40', 'scanobjectnn', 'shapenet55'])
 def test_fused_step_stream_vs_golden_and_oracle(ua, golden_dir, name):
     """predict+fit+fit in one pass, fed with the golden feature stream, WITHOUT residual learning
@@ -211,6 +231,58 @@ def test_clip_logits_matches_oracle(ua):
         np.testing.assert_allclose(p.cpu().numpy(), rp.numpy(), rtol=1e-4, atol=1e-7)
         assert abs(ent.item() - rent.item()) < 1e-5
         assert int(pred.item()) == int(rpred)
+
+
+def test_large_K_paths_are_bit_identical_to_the_one_workgroup_kernels(ua):
+    """K in the hundreds / thousands (BASELINE configs[3], [4]): the zero-shot logits run as rows-over-the-chip + a softmax
+    launch, the fusion with 1024 threads and block-wide arg-max / rank.  (a) wide clip path == single-workgroup kernel, bit
+    for bit (prob, entropy, arg-max; the single-workgroup kernel is selected by not passing a logits buffer);
+    (b) fusion at K = 4096 against the oracle, with a tie at the top to pin first-index arg-max and the rank rule;
+    (c) class-sharded pack + fuse from W = 8 buffers == ua_fuse_logits on the whole state, bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    for K in (256, 1156, 4096):
+        D, M, W = 1024, 16, 8
+        text = dev(torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1))
+        feat = dev((text[5:6].cpu() + 0.05 * torch.randn(1, D, generator=g)) * 2.5)
+        res = []
+        for wide in (True, False):
+            fh = torch.empty(1, D, device='cuda'); z = torch.empty(1, K, device='cuda'); p = torch.empty(1, K, device='cuda')
+            ent = torch.empty(1, device='cuda'); pred = torch.empty(1, dtype=torch.int32, device='cuda')
+            ua.call('ua_clip_logits', ua.ptr(feat), ua.ptr(text), K, D, 100.0, 1, ua.ptr(fh), ua.ptr(z) if wide else None, ua.ptr(p), ua.ptr(ent),
+                    ua.ptr(pred, torch.int32), ua.stream_ptr())
+            res.append((fh.cpu(), p.cpu(), ent.cpu(), pred.cpu()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b), K
+        # (b) fusion, with exact ties
+        clip = z.clone(); top = int(clip.argmax())
+        other = (top + 7) % K
+        clip[0, other] = clip[0, top]
+        dota = torch.randn(1, K, generator=g) * 30
+        dota[0, other] = dota[0, top]
+        c = torch.rand(K, M, generator=g) * 50
+        dotad, cd = dev(dota), dev(c)
+        want = O.fuse_logits(clip.cpu(), dota, c, 0.02, 0.1)
+        t = min(top, other) + 1 if min(top, other) + 1 != max(top, other) else min(top, other) + 2
+        tgt = torch.tensor([t % K], dtype=torch.int32, device='cuda')
+        out = torch.empty(1, K, device='cuda'); rank = torch.empty(1, dtype=torch.int32, device='cuda'); pred = torch.empty(1, dtype=torch.int32, device='cuda')
+        ua.call('ua_fuse_logits', ua.ptr(clip), ua.ptr(dotad), ua.ptr(cd), K, M, 0.02, 0.1, 1, ua.ptr(tgt, torch.int32), ua.ptr(out),
+                ua.ptr(rank, torch.int32), ua.ptr(pred, torch.int32), ua.stream_ptr())
+        o = out.cpu()
+        np.testing.assert_allclose(o.numpy(), want.numpy(), rtol=2e-5, atol=2e-4)
+        assert o[0, top] == o[0, other]
+        srt = sorted(range(K), key=lambda i: (-float(o[0, i]), i))
+        assert int(pred.item()) == srt[0] and int(rank.item()) == srt.index(int(tgt.item()))
+        # (c) sharded
+        per = -(-K // W)
+        gathered = torch.zeros(W, per + 2, device='cuda')
+        for r in range(W):
+            k0, k1 = min(r * per, K), min((r + 1) * per, K)
+            ua.call('ua_class_shard_pack', dotad.data_ptr() + 4 * k0, cd.data_ptr() + 4 * k0 * M, k1 - k0, M, per, gathered[r].data_ptr(), ua.stream_ptr())
+        out2 = torch.empty(1, K, device='cuda'); rank2 = torch.empty(1, dtype=torch.int32, device='cuda'); pred2 = torch.empty(1, dtype=torch.int32, device='cuda')
+        dz = torch.empty(1, K, device='cuda')
+        ua.call('ua_fuse_logits_sharded', ua.ptr(clip), ua.ptr(gathered), W, per, K, M, 0.02, 0.1, 1, ua.ptr(tgt, torch.int32), ua.ptr(out2),
+                ua.ptr(rank2, torch.int32), ua.ptr(pred2, torch.int32), ua.ptr(dz), ua.stream_ptr())
+        assert torch.equal(out2, out) and torch.equal(rank2, rank) and torch.equal(pred2, pred) and torch.equal(dz.cpu(), dota)
 
 
 # ------------------------------------------------------------------ residual learning kernels

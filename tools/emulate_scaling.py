@@ -18,12 +18,16 @@ def main():
     ap.add_argument('--priority', type=int, default=0)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--chunk', type=int, default=31)
-    ap.add_argument('--mode', default='replicated', choices=['replicated', 'owner', 'delta'])
+    ap.add_argument('--mode', default='replicated', choices=['replicated', 'owner', 'delta', 'class'])
     ap.add_argument('--rho', type=float, default=None)
+    ap.add_argument('--classes', type=int, default=0, help='synthetic text bank of this many classes instead of the ModelNet40 bank')
+    ap.add_argument('--modes', type=int, default=8)
+    ap.add_argument('--no-res', action='store_true', help='no residual learning (required for K > 160 and for --mode class)')
     a = ap.parse_args()
     dev = torch.device('cuda')
     gpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'g2_stream_modelnet40.npz')
-    text = torch.from_numpy(np.load(gpath)['text'])
+    text = torch.from_numpy(np.load(gpath)['text']) if not a.classes else synthetic.text_bank(a.classes, 1024, 1)
+    res = not a.no_res
     sd = synthetic.uni3d_state_dict(0, trans_dim=1024, embed_dim=1024, enc_dim=512, depth=24, device=dev)
     model = PE.create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16, device=dev, precision='split')
     n = a.chunk
@@ -88,8 +92,39 @@ def main():
                   f'{n * W / dt:8.1f} point-clouds/s whole job ({n / dt:6.1f} per GPU)', flush=True)
             del eng
         return
+    if a.mode == 'class':
+        # one rank of a W-rank 'class' job: encode its n samples, then per sample of the n*W-sample step its class slice of
+        # the cache step + the fusion from W stand-in buffers (its own, repeated; wire time of the tiny all_gather excluded)
+        for W in [int(w) for w in a.world.split(',')]:
+            eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, a.modes, res_learning=False, chunk=n * W,
+                            device=dev, replay_mode='class', emulated_rank=(0, max(W, 2)), overlap=True)
+            Wm = eng.world
+            total = a.steps + 2
+            xyz, rgb = synthetic.point_clouds(n * total, 1024, seed=42, device=dev)
+            noise = torch.randn(xyz.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+            final = torch.empty(n * W, eng.K, device=dev); preds = torch.empty(n * W, dtype=torch.int32, device=dev)
+            main_s, rs = torch.cuda.current_stream(), eng.replay_stream
+            eng.world = 1                                    # encode_chunk: all n samples are this rank's share
+            for it in range(total):
+                if it == 2:
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                s_ = slice(it * n, (it + 1) * n)
+                feats = eng.encode_chunk(xyz[s_], rgb[s_], noise[s_]).repeat(W, 1, 1).contiguous()
+                rs.wait_stream(main_s); feats.record_stream(rs)
+                eng.world = Wm
+                with torch.cuda.stream(rs):
+                    for j in range(n * W):
+                        buf = eng.class_local(feats[j, 0:1], feats[j, 1:2])
+                        eng.class_fuse(buf[None].repeat(Wm, 1), None, final[j:j + 1], None, preds[j:j + 1])
+                eng.world = 1
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.steps
+            print(f'W={W} class mode (K={eng.K}, M={eng.M}, {eng.class_k1 - eng.class_k0} classes on this rank): {dt * 1e3:7.1f} ms/step -> '
+                  f'{n * W / dt:8.1f} point-clouds/s whole job ({n / dt:6.1f} per GPU)', flush=True)
+            del eng
+        return
     for W in [int(w) for w in a.world.split(',')]:
-        eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, 8, res_learning=True, chunk=n * W, device=dev)
+        eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, a.modes, res_learning=res, chunk=n * W, device=dev)
         rs = torch.cuda.Stream(device=dev, priority=a.priority)
         total = a.steps + 2
         xyz, rgb = synthetic.point_clouds(n * total, 1024, seed=42, device=dev)

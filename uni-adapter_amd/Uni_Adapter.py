@@ -154,15 +154,27 @@ class TtaEngine:
         # where the sequential cache replay runs when W > 1 (stream.py): 'owner' = rank 0 only, with a
         # smaller encoder share for rank 0; 'replicated' = every rank replays everything
         self.replay_mode = replay_mode or os.environ.get('UA_REPLAY_MODE', 'owner')
-        if self.replay_mode not in ('owner', 'replicated', 'delta'):
-            raise ValueError(f"replay_mode must be 'owner', 'replicated' or 'delta', got {self.replay_mode!r}")
+        if self.replay_mode not in ('owner', 'replicated', 'delta', 'class'):
+            raise ValueError(f"replay_mode must be 'owner', 'replicated', 'class' or 'delta', got {self.replay_mode!r}")
+        # 'class' (exact, for large K): features are gathered as in 'replicated', but rank r keeps and
+        # updates only classes [r*per, (r+1)*per) of the GMM state; one small all_gather per SAMPLE re-assembles the scores
+        self.class_mode = self.replay_mode == 'class' and self.world > 1
+        if self.class_mode and self.res_learning:
+            raise ValueError("replay_mode='class' shards the GMM state by class; residual learning couples all classes "
+                             "(K x K alignment matrix) and is not available in this mode - pass res_learning=False")
         # 'delta' (SURVEY section 8e "prototype deltas", NOT exact): every rank replays only its own block from the common
         # state and one all_gather of sufficient-statistic deltas merges the W replicas after each step
         self.delta_mode = self.replay_mode == 'delta' and self.world > 1
         if self.delta_mode and not self.composite:
             raise ValueError("replay_mode='delta' needs the composite replay (log_alignment_every=0)")
         self.replay_cost_ratio = float(replay_cost_ratio)
-        self.replays = self.world == 1 or self.replay_mode in ('replicated', 'delta') or self.rank == 0
+        self.replays = self.world == 1 or self.replay_mode in ('replicated', 'delta', 'class') or self.rank == 0
+        if self.class_mode:
+            self.class_per = -(-self.K // self.world)
+            self.class_k0 = min(self.rank * self.class_per, self.K)
+            self.class_k1 = min(self.class_k0 + self.class_per, self.K)
+            self.xbuf = torch.zeros(self.class_per + 2, device=self.dev)
+            self.dz_local = torch.zeros(max(1, self.class_per), device=self.dev)
         self._delta = None
         K, D, M, dev = self.K, self.D, self.M, self.dev
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
@@ -299,6 +311,23 @@ class TtaEngine:
             self.i += n
             self.mode_dota_model.t += 2 * n
             return final.zero_(), ranks, preds.fill_(-1)
+        if self.class_mode:
+            main = torch.cuda.current_stream()
+            rs = self.replay_stream if self.overlap else main
+            if self.overlap:
+                rs.wait_stream(main)
+                for t in (feats, final, ranks, preds, tgt):
+                    if t is not None:
+                        t.record_stream(rs)
+            with torch.cuda.stream(rs):
+                for j in range(n):
+                    buf = self.class_local(feats[j, 0:1], feats[j, 1:2])
+                    self.class_fuse(gather_deltas(buf, self.world, self.group), tgt[j:j + 1] if tgt is not None else None,
+                                    final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
+                if tgt is not None:
+                    self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
+                    self.count += n
+            return final, ranks, preds
         if self.composite:
             # one host call enqueues the whole in-order replay of the chunk (csrc/ua_tta.hip)
             import ctypes
@@ -329,6 +358,36 @@ class TtaEngine:
             self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
             self.count += n
         return final, ranks, preds
+
+    # -- 'class' replay mode (exact, large K): per sample, this rank's class slice of the step, then the fusion from the
+    #    W gathered score slices (two halves so that W ranks can be driven in lock-step from one process) -------------
+    def class_local(self, feat, feat_aug):
+        """Clip logits over all K (every rank), predict + fit + fit on classes [k0,k1) of the state, pack the score slice
+        and the partial sum of c.  Returns the (per+2,) exchange buffer."""
+        K, M, D = self.K, self.M, self.D
+        k0, kl = self.class_k0, self.class_k1 - self.class_k0
+        mdl, st = self.mode_dota_model, lib.stream_ptr()
+        lib.call('ua_clip_logits_pair', lib.ptr(feat), lib.ptr(feat_aug), lib.ptr(self.text), K, D, LOGIT_SCALE, lib.ptr(self.fh),
+                 lib.ptr(self.fa), lib.ptr(self.z), lib.ptr(self.prob), st)                                   # :406,:424,:429
+        if kl:
+            row = 4 * k0 * M
+            lib.call('ua_gmm_step_fused', mdl.mu.data_ptr() + row * D, mdl.var.data_ptr() + row * D, mdl.pi.data_ptr() + row,
+                     mdl.c.data_ptr() + row, mdl.class_counts.data_ptr() + 4 * k0, lib.ptr(self.fh), 1, lib.ptr(self.fh),
+                     lib.ptr(self.fa), self.prob.data_ptr() + 4 * k0, lib.ptr(self.dz_local), kl, M, D, mdl.epsilon, st)   # :416,:417,:430
+        lib.call('ua_class_shard_pack', lib.ptr(self.dz_local), mdl.c.data_ptr() + 4 * k0 * M, kl, M, self.class_per,
+                 lib.ptr(self.xbuf), st)
+        return self.xbuf
+
+    def class_fuse(self, gathered, target, out_final, out_rank, out_pred):
+        """gathered: (W, per+2) = every rank's class_local buffer in rank order."""
+        gathered = gathered.contiguous()
+        assert gathered.shape == (self.world, self.class_per + 2)
+        lib.call('ua_fuse_logits_sharded', lib.ptr(self.z), lib.ptr(gathered), self.world, self.class_per, self.K, self.M,
+                 float(self.cfg['rho']), float(self.cfg['eta']), 1, lib.ptr(target, torch.int32) if target is not None else None,
+                 lib.ptr(out_final), lib.ptr(out_rank, torch.int32) if target is not None else None, lib.ptr(out_pred, torch.int32),
+                 lib.ptr(self.dz), lib.stream_ptr())                                                          # :491-521
+        self.i += 1
+        self.mode_dota_model.t += 2
 
     # -- 'delta' replay mode: local replay + pack, exchange, merge (three steps so that W ranks can also be driven in
     #    lock-step from one process: tests/test_gpu_harness.py, tools/emulate_scaling.py) ---------------------------
@@ -442,6 +501,8 @@ class TtaEngine:
         """Everything the stream carries from sample to sample: GMM state, text residuals and their Adam
         moments, counters.  Plain tensors / ints (loadable with torch.load(weights_only=True))."""
         self.synchronize()
+        if self.class_mode:
+            raise NotImplementedError("state_dict() in replay_mode='class': each rank holds only its class slice of the state")
         m, r = self.mode_dota_model, self.residuals
         sd = {'version': 1, 'K': self.K, 'M': self.M, 'D': self.D, 'i': int(self.i), 't': int(m.t), 'count': int(self.count),
               'correct': self.correct.detach().cpu().clone(),

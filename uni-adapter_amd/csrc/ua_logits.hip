@@ -40,6 +40,23 @@ __device__ float softmax_entropy_lds(const float* z, float* p, int K, double* sd
     return -(float)block_sum(h, sd);
 }
 
+// arg-max with the first index winning ties (the serial `if (z[i] > z[b]) b = i` scan), block-wide; result valid on thread 0
+__device__ int block_argmax_first(const float* z, int K, float* sf, int* si) {
+    float best = -INFINITY; int idx = 0x7fffffff;
+    if ((int)threadIdx.x < K) { best = z[threadIdx.x]; idx = threadIdx.x; }
+    for (int i = threadIdx.x + blockDim.x; i < K; i += blockDim.x) if (z[i] > best) { best = z[i]; idx = i; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(idx, o);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sf[w] = best; si[w] = idx; }
+    __syncthreads();
+    for (int i = 0; i < nw; ++i) if (sf[i] > best || (sf[i] == best && si[i] < idx)) { best = sf[i]; idx = si[i]; }
+    return idx;
+}
+
 // ------------------------------------------------------------------------------------------
 // get_logits_wrapper, one workgroup of 256 threads.  dynamic LDS: D + 2K floats.
 // ------------------------------------------------------------------------------------------
@@ -90,29 +107,81 @@ clip_logits_kernel(ClipArgs a) {
         if (j.logits) j.logits[i] = z[i];
         if (j.prob) j.prob[i] = p[i];
     }
-    if (threadIdx.x == 0) {
-        if (j.entropy) *j.entropy = h;
-        if (j.pred) { int b = 0; for (int i = 1; i < K; ++i) if (z[i] > z[b]) b = i; *j.pred = b; }
+    if (j.pred) {                                          // uniform branch
+        __shared__ int si[16];
+        const int b = block_argmax_first(z, K, sf, si);
+        if (threadIdx.x == 0) *j.pred = b;
     }
+    if (threadIdx.x == 0 && j.entropy) *j.entropy = h;
+}
+
+// Large K (hundreds of classes and more): the (K,D) text bank no longer fits one workgroup's time budget (16 MB at
+// K = 4096), so the rows are spread over the chip - grid (ceil(K/16), jobs), wave = one class row, same per-row
+// arithmetic as above - and a second one-workgroup launch does the softmax / entropy / arg-max on the K logits.
+// Results are bit-identical to clip_logits_kernel.
+__global__ void __launch_bounds__(1024)
+clip_rows_kernel(ClipArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    const ClipJob j = a.job[blockIdx.y];
+    const int K = a.K, D = a.D, nt = blockDim.x;
+    const float scale = a.scale;
+    if (!j.logits && blockIdx.x != 0) return;              // this job only wants fhat
+    float* f = smem;
+    for (int i = threadIdx.x; i < D; i += nt) f[i] = j.feat[i];
+    __syncthreads();
+    for (int r = 0; r < j.n_norm; ++r) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < D; i += nt) s += (double)(f[i] * f[i]);
+        const float nrm = (float)sqrt(block_sum(s, sd));
+        for (int i = threadIdx.x; i < D; i += nt) f[i] = f[i] / nrm;
+        __syncthreads();
+    }
+    if (j.fhat && blockIdx.x == 0) for (int i = threadIdx.x; i < D; i += nt) j.fhat[i] = f[i];
+    if (!j.logits) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = nt >> 6;
+    const int k = blockIdx.x * nw + w;
+    if (k >= K) return;
+    const float4* t4 = reinterpret_cast<const float4*>(a.text + (size_t)k * D);
+    double acc = 0.0;
+    for (int i = lane; i < D / 4; i += 64) {
+        const float4 t = t4[i];
+        acc += (double)((scale * f[4 * i + 0]) * t.x) + (double)((scale * f[4 * i + 1]) * t.y)
+             + (double)((scale * f[4 * i + 2]) * t.z) + (double)((scale * f[4 * i + 3]) * t.w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) j.logits[k] = (float)acc;
+}
+
+__global__ void __launch_bounds__(1024)
+clip_softmax_kernel(ClipArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    __shared__ int si[16];
+    const ClipJob j = a.job[blockIdx.x];
+    if (!j.logits || (!j.prob && !j.entropy && !j.pred)) return;
+    const int K = a.K, nt = blockDim.x;
+    float* z = smem; float* p = smem + K;
+    for (int i = threadIdx.x; i < K; i += nt) z[i] = j.logits[i];
+    __syncthreads();
+    const float h = softmax_entropy_lds(z, p, K, sd, sf);
+    __syncthreads();
+    if (j.prob) for (int i = threadIdx.x; i < K; i += nt) j.prob[i] = p[i];
+    if (j.pred) {
+        const int b = block_argmax_first(z, K, sf, si);
+        if (threadIdx.x == 0) *j.pred = b;
+    }
+    if (threadIdx.x == 0 && j.entropy) *j.entropy = h;
 }
 
 // ------------------------------------------------------------------------------------------
 // Fusion, one workgroup.  dynamic LDS: 3K floats.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-fuse_logits_kernel(const float* __restrict__ clip, const float* __restrict__ dota, const float* __restrict__ c,
-                   int K, int M, float rho, float eta, int batch, const int* __restrict__ target,
-                   float* __restrict__ final_logits, int* __restrict__ rank, int* __restrict__ pred) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ double sd[16];
-    __shared__ float sf[16];
-    float* zc = smem; float* zd = smem + K; float* p = smem + 2 * K;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < K * M; i += 256) s += (double)c[i];
-    const float cmean = (float)(block_sum(s, sd) / (double)(K * M));
-    const float w = fminf(rho * cmean / (float)batch, eta);                      // :491
-    for (int i = threadIdx.x; i < K; i += 256) { zc[i] = clip[i]; zd[i] = w * dota[i]; }   // :498
-    __syncthreads();
+// everything after the fusion weight: zc / zd hold clip and w*dota (K each), p is scratch (K)
+__device__ __forceinline__ void fuse_core(float* zc, float* zd, float* p, int K, double* sd, float* sf,
+                                          const int* __restrict__ target, float* __restrict__ final_logits,
+                                          int* __restrict__ rank, int* __restrict__ pred) {
     const float hc = softmax_entropy_lds(zc, p, K, sd, sf);                      // :508
     __syncthreads();
     const float hd = softmax_entropy_lds(zd, p, K, sd, sf);                      // :509
@@ -121,22 +190,79 @@ fuse_logits_kernel(const float* __restrict__ clip, const float* __restrict__ dot
     wc = wc / (wc + wd);                                                         // :512
     wd = wd / (wc + wd);                                                         // :513 (reuses new wc)
     __syncthreads();
-    for (int i = threadIdx.x; i < K; i += 256) {
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const float v = wc * zc[i] + wd * zd[i];                                 // :521
         p[i] = v;
         final_logits[i] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (pred) { int b = 0; for (int i = 1; i < K; ++i) if (p[i] > p[b]) b = i; *pred = b; }
-        if (rank && target) {
-            const int t = *target;
-            int rk = 0;
-            if (t >= 0 && t < K) { for (int i = 0; i < K; ++i) rk += (p[i] > p[t]) || (p[i] == p[t] && i < t); }
-            else rk = K;
-            *rank = rk;
-        }
+    if (pred) {                                                                  // uniform branches
+        __shared__ int si[16];
+        const int b = block_argmax_first(p, K, sf, si);
+        if (threadIdx.x == 0) *pred = b;
     }
+    if (rank && target) {                                                        // utils/utils.py:154-167
+        const int t = *target;
+        double rk = 0.0;
+        if (t >= 0 && t < K) { for (int i = threadIdx.x; i < K; i += blockDim.x) rk += (p[i] > p[t]) || (p[i] == p[t] && i < t); }
+        __syncthreads();
+        rk = block_sum(rk, sd);
+        if (threadIdx.x == 0) *rank = (t >= 0 && t < K) ? (int)rk : K;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+fuse_logits_kernel(const float* __restrict__ clip, const float* __restrict__ dota, const float* __restrict__ c,
+                   int K, int M, float rho, float eta, int batch, const int* __restrict__ target,
+                   float* __restrict__ final_logits, int* __restrict__ rank, int* __restrict__ pred) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    float* zc = smem; float* zd = smem + K; float* p = smem + 2 * K;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < K * M; i += blockDim.x) s += (double)c[i];
+    const float cmean = (float)(block_sum(s, sd) / (double)(K * M));
+    const float w = fminf(rho * cmean / (float)batch, eta);                      // :491
+    for (int i = threadIdx.x; i < K; i += blockDim.x) { zc[i] = clip[i]; zd[i] = w * dota[i]; }   // :498
+    __syncthreads();
+    fuse_core(zc, zd, p, K, sd, sf, target, final_logits, rank, pred);
+}
+
+// Class-sharded replay (large K): rank r owns classes [r*per, min((r+1)*per, K)) of the state.
+// pack: this rank's score slice + the fp64 sum of its slice of c as a (hi, lo) float pair -> out (per + 2 floats).
+__global__ void __launch_bounds__(256)
+class_shard_pack_kernel(const float* __restrict__ scores, const float* __restrict__ c, int Kl, int M, int per,
+                        float* __restrict__ out) {
+    __shared__ double sd[16];
+    for (int i = threadIdx.x; i < per; i += 256) out[i] = i < Kl ? scores[i] : 0.f;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < Kl * M; i += 256) s += (double)c[i];
+    s = block_sum(s, sd);
+    if (threadIdx.x == 0) { const float hi = (float)s; out[per] = hi; out[per + 1] = (float)(s - (double)hi); }
+}
+
+// fuse from the W gathered buffers (rank order): dota scores re-assembled, mean(c) from the partial sums.
+__global__ void __launch_bounds__(1024)
+fuse_logits_sharded_kernel(const float* __restrict__ clip, const float* __restrict__ gathered, int W, int per,
+                           int K, int M, float rho, float eta, int batch, const int* __restrict__ target,
+                           float* __restrict__ final_logits, int* __restrict__ rank, int* __restrict__ pred,
+                           float* __restrict__ dota_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double sd[16];
+    __shared__ float sf[16];
+    float* zc = smem; float* zd = smem + K; float* p = smem + 2 * K;
+    double s = 0.0;
+    for (int r = 0; r < W; ++r) s += (double)gathered[(size_t)r * (per + 2) + per] + (double)gathered[(size_t)r * (per + 2) + per + 1];
+    const float cmean = (float)(s / (double)(K * M));
+    const float w = fminf(rho * cmean / (float)batch, eta);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const int r = i / per;
+        const float d = gathered[(size_t)r * (per + 2) + (i - r * per)];
+        if (dota_out) dota_out[i] = d;
+        zc[i] = clip[i]; zd[i] = w * d;
+    }
+    __syncthreads();
+    fuse_core(zc, zd, p, K, sd, sf, target, final_logits, rank, pred);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -229,6 +355,22 @@ static int launch_clip(const ClipArgs& a, int jobs, void* stream) {
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(clip_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return UA_ELAUNCH;
+    bool wide = a.K >= 256;
+    for (int i = 0; i < jobs; ++i) {
+        const ClipJob& j = a.job[i];
+        if ((j.prob || j.entropy || j.pred) && !j.logits) wide = false;     // the wide path keeps the logits in the caller's buffer
+    }
+    if (wide) {
+        hipLaunchKernelGGL(clip_rows_kernel, dim3((a.K + 15) / 16, jobs), dim3(1024), (size_t)a.D * sizeof(float), ua::as_stream(stream), a);
+        UA_LAUNCH_CHECK();
+        const size_t lds2 = (size_t)(2 * a.K) * sizeof(float);
+        if (lds2 > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(clip_softmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds2) != hipSuccess) return UA_ELAUNCH;
+        hipLaunchKernelGGL(clip_softmax_kernel, dim3(jobs), dim3(1024), lds2, ua::as_stream(stream), a);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    }
     hipLaunchKernelGGL(clip_logits_kernel, dim3(jobs), dim3(1024), lds, ua::as_stream(stream), a);
     UA_LAUNCH_CHECK();
     return UA_OK;
@@ -264,8 +406,37 @@ extern "C" int ua_fuse_logits(const float* clip_logits, const float* dota_logits
     if (K <= 0 || M <= 0 || batch <= 0) return UA_EINVAL;
     const size_t lds = (size_t)(3 * K) * sizeof(float);
     if (lds > 150 * 1024) return UA_EUNSUPPORTED;
-    hipLaunchKernelGGL(fuse_logits_kernel, dim3(1), dim3(256), lds, ua::as_stream(stream),
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fuse_logits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return UA_ELAUNCH;
+    hipLaunchKernelGGL(fuse_logits_kernel, dim3(1), dim3(K > 1024 ? 1024 : 256), lds, ua::as_stream(stream),
                        clip_logits, dota_logits, c, K, M, rho, eta, batch, target, final_logits, rank, pred);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_class_shard_pack(const float* scores, const float* c, int32_t K_local, int32_t M, int32_t per, float* out,
+                                   void* stream) {
+    UA_CHECK_PTR(out);
+    if (K_local < 0 || K_local > per || per <= 0 || M <= 0) return UA_EINVAL;
+    if (K_local > 0) { UA_CHECK_PTR(scores); UA_CHECK_PTR(c); }
+    hipLaunchKernelGGL(class_shard_pack_kernel, dim3(1), dim3(256), 0, ua::as_stream(stream), scores, c, K_local, M, per, out);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+extern "C" int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t per, int32_t K, int32_t M,
+                                      float rho, float eta, int32_t batch, const int32_t* target, float* final_logits,
+                                      int32_t* rank, int32_t* pred, float* dota_out, void* stream) {
+    UA_CHECK_PTR(clip_logits); UA_CHECK_PTR(gathered); UA_CHECK_PTR(final_logits);
+    if (K <= 0 || M <= 0 || batch <= 0 || W <= 0 || per <= 0 || (int64_t)W * per < K) return UA_EINVAL;
+    const size_t lds = (size_t)(3 * K) * sizeof(float);
+    if (lds > 150 * 1024) return UA_EUNSUPPORTED;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fuse_logits_sharded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return UA_ELAUNCH;
+    hipLaunchKernelGGL(fuse_logits_sharded_kernel, dim3(1), dim3(K > 1024 ? 1024 : 256), lds, ua::as_stream(stream),
+                       clip_logits, gathered, W, per, K, M, rho, eta, batch, target, final_logits, rank, pred, dota_out);
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

@@ -17,7 +17,13 @@ Two ways to place the sequential part:
     rho = (marginal replay ms per sample) / (encoder ms per sample) ~ 0.15 on MI355X, so that all ranks
     finish a step together (W = 8: rank 0 encodes nothing and replays 248 samples in 74 ms while seven
     ranks encode 35-36 samples each).  Results live on rank 0; accuracies are broadcast at the end.
-Both give results identical to the single-process stream.
+  * 'class' (exact, for large K such as the 1 156-class or 4 096-class banks): features are gathered as in 'replicated', but
+    rank r keeps and updates only classes [r*per, (r+1)*per), per = ceil(K/W), of the GMM state - every formula of the cache
+    step is independent per class; the couplings are the softmax over K of the zero-shot logits (computed on every rank)
+    and mean(c) in the fusion weight.  One small all_gather per SAMPLE ((per + 2) floats per rank: the score slice and
+    the partial sum of c) re-assembles the scores; the state traffic per sample drops by W.  No residual learning (its
+    K x K alignment matrix couples all classes, and is infeasible at such K in the reference as well).
+All three give results identical to the single-process stream.
   * 'delta' (opt-in, NOT exact; the north star's "all-gather of per-rank prototype deltas after each chunk"): every rank
     replays only its own even block of the step from the common state S0 and ONE all_gather of the packed
     sufficient-statistic deltas (dC, dS1 = d(c*mu), dS2 = d(c*var), class counts, text residuals + Adam moments;
@@ -80,6 +86,10 @@ def gather_deltas(buf, world, group=None):
     on every rank; the merge kernel sums the rows in rank order, so the result does not depend on the collective's algorithm."""
     if world == 1:
         return buf[None]
+    if buf.is_cuda and torch.distributed.get_backend(group) != 'gloo':
+        out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+        torch.distributed.all_gather_into_tensor(out, buf.contiguous(), group=group)       # RCCL, one flat receive buffer
+        return out
     return torch.stack(_all_gather(buf, world, group), 0)
 
 
