@@ -133,3 +133,50 @@ def test_driver_end_to_end_and_resume(tmp_path):
     assert resumed.accuracy() == full.accuracy()
     with pytest.raises(ValueError):
         TtaEngine(model, text, cfg, 4, res_learning=True, chunk=6, device=torch.device('cuda')).load_state_dict(torch.load(ck, weights_only=True))
+
+
+def _driver_worker(rank, world, port, root, mode):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), UA_REPLAY_MODE=mode)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import uni_adapter_amd  # noqa: F401
+    res = _drive(root, f'run_{mode}_r{rank}')
+    torch.save(res, os.path.join(root, f'res_{mode}_r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def _drive(root, name):
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.main_test_time import parse_args, run
+    sd = synthetic.uni3d_state_dict(3, trans_dim=128, embed_dim=256, depth=1, device='cuda')
+    model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    a = parse_args(['--myroot', root, '--dataset_name', 'scanobject', '--corruption', 'gaussian', '--mode-M', '2',
+                    '--precomputed-text-features', os.path.join(root, 'text.pt'), '--output-dir', os.path.join(root, 'out'),
+                    '--name', name, '--chunk-size', '5'])
+    return run(a, model=model)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['owner', 'replicated'])
+def test_driver_two_ranks_equals_single_process(tmp_path, mode):
+    """The driver as one rank of a 2-process job (both on cuda:0, gloo): every rank reads the same corruption stream and
+    draws the same augmentation noise, the engine shards the samples; both ranks report the single-process accuracy."""
+    import socket
+    import torch.multiprocessing as mp
+    from uni_adapter_amd import synthetic
+    K, n = 15, 12
+    g = np.random.default_rng(2)
+    pts = g.standard_normal((n, 1024, 3)).astype(np.float32)
+    pts /= np.linalg.norm(pts, axis=-1).max(axis=1)[:, None, None]
+    np.save(os.path.join(tmp_path, 'data_gaussian_5.npy'), pts)
+    np.save(os.path.join(tmp_path, 'label.npy'), g.integers(0, K, size=(n, 1)))
+    torch.save(synthetic.text_bank(K, 256, seed=4), os.path.join(tmp_path, 'text.pt'))
+    want = _drive(str(tmp_path), 'single')
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_driver_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(os.path.join(tmp_path, f'res_{mode}_r{r}.pt'), weights_only=True) == want

@@ -56,7 +56,12 @@ def parse_args(argv=None):
     p.add_argument('--chunk-size', type=int, default=16, help='samples encoded per batch (the cache replay stays in stream order)')
     p.add_argument('--gemm-precision', type=str, default='split', choices=['split', 'f32'])
     p.add_argument('--mmap', action='store_true', help='memory-map the corruption .npy instead of reading it')
-    return p.parse_args(argv)
+    p.add_argument('--replay-mode', type=str, default=None, choices=['owner', 'replicated', 'class', 'delta'],
+                   help='multi-GPU placement of the cache replay (uni_adapter_amd/stream.py); default owner, or UA_REPLAY_MODE')
+    args = p.parse_args(argv)
+    if args.replay_mode:
+        os.environ['UA_REPLAY_MODE'] = args.replay_mode
+    return args
 
 
 def random_seed(seed=42, rank=0):
@@ -95,7 +100,26 @@ def run(args, model=None):
 
 
 def main(argv=None):
-    run(parse_args(argv))
+    """Single process, or one rank of `python -m torch.distributed.run --nproc-per-node N -m uni_adapter_amd.main_test_time ...`
+    (one process per GPU, RCCL): every rank reads the same stream, `TtaEngine` shards it (stream.py)."""
+    args = parse_args(argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+        args.device = f'cuda:{local % max(1, torch.cuda.device_count())}'
+        torch.cuda.set_device(args.device)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = os.environ.get('UA_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=torch.device(args.device))
+        else:
+            torch.distributed.init_process_group(backend)
+        args.name = f"{args.name or datetime.now().strftime('%Y_%m_%d-%H_%M')}_rank{rank}"      # one log directory per rank
+    try:
+        run(args)
+    finally:
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
