@@ -52,6 +52,16 @@ __device__ __forceinline__ void store_row(const Row<VEC>& r, float* mu, float* v
 
 __device__ __forceinline__ float reg_var(float v, float eps) { return fmaxf(v + eps, 1e-8f); }   // :117-119
 
+// a / b for the streaming kernels: the full IEEE sequence (v_div_scale x2, v_rcp, 5 x v_fma, v_div_fmas, v_div_fixup) was
+// 55 % of gmm_step_kernel's VALU instructions and the kernel is VALU-bound.  Here: hardware reciprocal (1 ulp) and one
+// residual correction, q = a*r;  q += (a - q*b)*r  - error 0.5 ulp + O(2^-46), i.e. the correctly rounded quotient except
+// in rare double-rounding cases.  Divisors on this path are normal numbers in [1e-8, 1e6] (regularised variances, counts).
+__device__ __forceinline__ float div_r(float a, float b, float r) {
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, a), r, q);
+}
+__device__ __forceinline__ float div_nr(float a, float b) { return div_r(a, b, __builtin_amdgcn_rcpf(b)); }
+
 // sum_d ln(max(var+eps,1e-8)) over the wave's row (all lanes get the total)
 template <int VEC>
 __device__ __forceinline__ double row_logdet(const Row<VEC>& r, float eps) {
@@ -78,10 +88,10 @@ __device__ __forceinline__ double row_maha(const Row<VEC>& r, const float* x, fl
         float4 xv = px[v * 64 + lane];
         if (ROUND16) { xv.x = round_fp16(xv.x); xv.y = round_fp16(xv.y); xv.z = round_fp16(xv.z); xv.w = round_fp16(xv.w); }
         float d;
-        d = xv.x - r.mu[v].x; acc += (double)((d * d) / reg_var(r.var[v].x, eps));
-        d = xv.y - r.mu[v].y; acc += (double)((d * d) / reg_var(r.var[v].y, eps));
-        d = xv.z - r.mu[v].z; acc += (double)((d * d) / reg_var(r.var[v].z, eps));
-        d = xv.w - r.mu[v].w; acc += (double)((d * d) / reg_var(r.var[v].w, eps));
+        d = xv.x - r.mu[v].x; acc += (double)div_nr(d * d, reg_var(r.var[v].x, eps));
+        d = xv.y - r.mu[v].y; acc += (double)div_nr(d * d, reg_var(r.var[v].y, eps));
+        d = xv.z - r.mu[v].z; acc += (double)div_nr(d * d, reg_var(r.var[v].z, eps));
+        d = xv.w - r.mu[v].w; acc += (double)div_nr(d * d, reg_var(r.var[v].w, eps));
     }
     return wave_sum(acc);
 }
@@ -200,12 +210,13 @@ __global__ void __launch_bounds__(1024) gmm_step_kernel(StepArgs a) {
         }
         const float c_new = c_km + sum_gamma;                                          // :196
         const float den = c_new + 1e-10f;
+        const float rden = __builtin_amdgcn_rcpf(den);
 #define UA_UPD(F)                                                                                     \
         {                                                                                             \
             const float mo = r.mu[v].F, vo = r.var[v].F, w1 = wx[v].F, w2 = wxx[v].F;                 \
-            const float mn = (c_km * mo + w1) / den;                                   /* :205-206 */ \
+            const float mn = div_r(c_km * mo + w1, den, rden);                         /* :205-206 */ \
             const float sq = (w2 + (-2.0f * mo) * w1) + sum_gamma * (mo * mo);         /* :215-217 */ \
-            const float vn = (c_km * vo + sq) / den;                                   /* :219-220 */ \
+            const float vn = div_r(c_km * vo + sq, den, rden);                         /* :219-220 */ \
             r.mu[v].F = mn; r.var[v].F = fmaxf(vn, 1e-8f);                             /* :223     */ \
         }
 #pragma unroll
