@@ -119,6 +119,32 @@ def test_gmm_fit_gamma_zero_is_identity_and_errors(ua):
         ua.call('ua_gmm_fit', None, ua.ptr(var), ua.ptr(pi), ua.ptr(c), ua.ptr(cc), ua.ptr(x), ua.ptr(z), 1, 6, 4, 256, 1e-4, ua.stream_ptr())
 
 
+@pytest.mark.parametrize('K,M,D', [(5, 4, 256), (40, 8, 1024), (300, 16, 1024), (700, 8, 512)])
+def test_stream_step_kernel_is_bit_identical_to_the_generic_one(ua, K, M, D):
+    """ua_gmm_step_fused runs the persistent single-sample kernel (classes round-robin over at most 256 workgroups, next
+    class prefetched); ua_gmm_loglik + ua_gmm_fit + ua_gmm_fit run the generic kernels.  Same scores and same state, bit
+    for bit, over several consecutive samples (K > 256 makes workgroups loop)."""
+    text, st, g = _stream_state(K, M, D, 3, 17)
+    A = [dev(t.clone()) for t in (st.mu, st.var, st.pi, st.c, st.class_counts)]
+    B = [dev(t.clone()) for t in (st.mu, st.var, st.pi, st.c, st.class_counts)]
+    for it in range(3):
+        lab = int(torch.randint(0, K, (1,), generator=g))
+        x1 = torch.nn.functional.normalize(text[lab:lab + 1] + 0.05 * torch.randn(1, D, generator=g), dim=1)
+        x2 = torch.nn.functional.normalize(text[lab:lab + 1] + 0.05 * torch.randn(1, D, generator=g), dim=1)
+        xq = x1.half().float()
+        prob = torch.softmax(100 * x1 @ text.T, 1)
+        x1d, x2d, xqd, pd = dev(x1), dev(x2), dev(xq), dev(prob)
+        sa, sb = torch.empty(1, K, device='cuda'), torch.empty(1, K, device='cuda')
+        ua.call('ua_gmm_step_fused', *(ua.ptr(t) for t in A), ua.ptr(x1d), 1, ua.ptr(x1d), ua.ptr(x2d), ua.ptr(pd), ua.ptr(sa), K, M, D, 1e-4,
+                ua.stream_ptr())
+        ua.call('ua_gmm_loglik', ua.ptr(B[0]), ua.ptr(B[1]), ua.ptr(B[2]), ua.ptr(xqd), 1, K, M, D, 1e-4, ua.ptr(sb), None, None, ua.stream_ptr())
+        for xx in (x1d, x2d):
+            ua.call('ua_gmm_fit', *(ua.ptr(t) for t in B), ua.ptr(xx), ua.ptr(pd), 1, K, M, D, 1e-4, ua.stream_ptr())
+        assert torch.equal(sa, sb), it
+        for a, b in zip(A, B):
+            assert torch.equal(a, b), it
+
+
 def test_predict_is_invariant_to_mode_permutation(ua):
     """SURVEY section 8c property: relabelling the M modes of every class changes nothing but the order of the terms of
     the logsumexp over modes; the per-mode joint log-probabilities are permuted exactly."""

@@ -62,16 +62,26 @@ __device__ __forceinline__ float div_r(float a, float b, float r) {
 }
 __device__ __forceinline__ float div_nr(float a, float b) { return div_r(a, b, __builtin_amdgcn_rcpf(b)); }
 
+// logf for a NORMAL, finite, positive argument (regularised variances are >= 1e-8): the compiler's own expansion of logf -
+// v_log_f32, then ln2 applied as a (hi, lo) pair, r = y*c; r += fma(y, cc, fma(y, c, -r)) - without its denormal pre-scaling
+// (compare, select, ldexp, select, subtract) and infinity select, 5 instead of 12 instructions, same bits for such arguments.
+__device__ __forceinline__ float log_normal(float x) {
+    const float y = __builtin_amdgcn_logf(x);
+    const float c = __uint_as_float(0x3f317217u), cc = __uint_as_float(0x3377d1cfu);
+    const float r = y * c;
+    return r + __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
+}
+
 // sum_d ln(max(var+eps,1e-8)) over the wave's row (all lanes get the total)
 template <int VEC>
 __device__ __forceinline__ double row_logdet(const Row<VEC>& r, float eps) {
     double acc = 0.0;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        acc += (double)logf(reg_var(r.var[v].x, eps));
-        acc += (double)logf(reg_var(r.var[v].y, eps));
-        acc += (double)logf(reg_var(r.var[v].z, eps));
-        acc += (double)logf(reg_var(r.var[v].w, eps));
+        acc += (double)log_normal(reg_var(r.var[v].x, eps));
+        acc += (double)log_normal(reg_var(r.var[v].y, eps));
+        acc += (double)log_normal(reg_var(r.var[v].z, eps));
+        acc += (double)log_normal(reg_var(r.var[v].w, eps));
     }
     return wave_sum(acc);
 }
@@ -102,6 +112,47 @@ __device__ __forceinline__ float lse_modes(const float* j, int M) {
     for (int i = 1; i < M; ++i) mx = fmaxf(mx, j[i]);
     float s = 0.f;
     for (int i = 0; i < M; ++i) s += expf(j[i] - mx);
+    return mx + logf(s);
+}
+
+// row_logdet and one or two row_maha in ONE pass over the row: the regularised variance and its reciprocal are formed
+// once per element.  Each accumulator sees the same terms in the same order as the separate passes: same bits.
+template <int VEC, bool TWO>
+__device__ __forceinline__ void row_logdet_maha(const Row<VEC>& r, const float* xa, const float* xb, float eps, int lane,
+                                                double& ld, double& ma, double& mb) {
+    const float4* pa = reinterpret_cast<const float4*>(xa);
+    const float4* pb = reinterpret_cast<const float4*>(xb);
+    double al = 0.0, aa = 0.0, ab = 0.0;
+#define UA_LM(F)                                                                        \
+    {                                                                                   \
+        const float rv = reg_var(r.var[v].F, eps);                                      \
+        const float rc = __builtin_amdgcn_rcpf(rv);                                     \
+        al += (double)log_normal(rv);                                                   \
+        float d = xav.F - r.mu[v].F; aa += (double)div_r(d * d, rv, rc);                \
+        if (TWO) { d = xbv.F - r.mu[v].F; ab += (double)div_r(d * d, rv, rc); }         \
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float4 xav = pa[v * 64 + lane];
+        float4 xbv = xav;
+        if (TWO) xbv = pb[v * 64 + lane];
+        UA_LM(x) UA_LM(y) UA_LM(z) UA_LM(w)
+    }
+#undef UA_LM
+    ld = wave_sum(al); ma = wave_sum(aa);
+    if (TWO) mb = wave_sum(ab);
+}
+
+// lse_modes with the work spread over the wave: lane i < M forms expf(j[i] - max), the sum is then taken in the same
+// left-to-right order through v_readlane, so the result has the same bits as lse_modes (the maximum is exact in any
+// order).  ~95 instead of ~200 instructions for M = 16 - a quarter of gmm_step1_kernel's instruction stream otherwise,
+// as every wave needs the value.  All 64 lanes must be active; M <= 64.
+__device__ __forceinline__ float lse_modes_wave(const float* j, int M, int lane) {
+    const float v = lane < M ? j[lane] : -INFINITY;
+    const float mx = ua::wave_max(v);
+    const float e = lane < M ? expf(v - mx) : 0.f;
+    float s = 0.f;
+    for (int i = 0; i < M; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), i));
     return mx + logf(s);
 }
 
@@ -241,6 +292,110 @@ __global__ void __launch_bounds__(1024) gmm_step_kernel(StepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The stream case of the step kernel - one query, two single-sample fits (Uni_Adapter.py:416,417,430) - as a
+// grid-stride loop over classes with the NEXT class's rows prefetched into registers while the current class is
+// computed, and the updated rows stored asynchronously: with one 1024-thread workgroup per CU the generic kernel
+// runs load -> compute -> store back to back (VALU idle while loading, HBM idle while computing).  Without the
+// per-fit accumulators of the batched path (for B = 1, sum_b g*x is g*x) the rows of two classes fit the 128-VGPR
+// budget of a 1024-thread workgroup.  Same expressions in the same order as gmm_step_kernel: bit-identical state
+// and scores (tests/test_gpu_kernels.py::test_stream_step_kernel_is_bit_identical_to_the_generic_one).
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
+    constexpr int D = 256 * VEC;
+    __shared__ __attribute__((aligned(16))) float s_x[3][D];     // query (fp16-rounded if asked), sample, augmented sample
+    __shared__ float s_j[kMaxModes];
+    __shared__ float s_c[kMaxModes];
+    const int m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int M = a.M, K = a.K;
+    const float eps = a.eps;
+    // Everything a class needs from global memory is requested one class ahead: the vector-memory counter retires in
+    // order, so ANY later load inside the class body would also wait for the prefetched rows and undo the overlap.
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float q = a.xq[i];
+        s_x[0][i] = a.round_q ? round_fp16(q) : q;
+        s_x[1][i] = a.xf[0][i];
+        s_x[2][i] = a.xf[1][i];
+    }
+    Row<VEC> r, nx;
+    int k = blockIdx.x;
+    float c_km = 0.f, pi_km = 0.f, g0 = 0.f, g1 = 0.f, cc = 0.f;
+    float c_nx = 0.f, pi_nx = 0.f, g0_nx = 0.f, g1_nx = 0.f, cc_nx = 0.f;
+    if (k < K) {
+        c_km = a.c[k * M + m]; pi_km = a.pi[k * M + m]; g0 = a.gf[0][k]; g1 = a.gf[1][k]; cc = a.class_counts[k];
+        load_row<VEC>(r, a.mu, a.var, ((size_t)k * M + m) * D, lane);
+    }
+    // first class resident before the loop: otherwise the compiler's wait for these loads sits at the first use inside the
+    // loop body and - the counter being in-order, and the prefetch below conditional - also waits for the prefetch there
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
+    __syncthreads();
+    for (; k < K; k += gridDim.x) {
+        const int kn = k + gridDim.x;
+        if (kn < K) {
+            c_nx = a.c[kn * M + m]; pi_nx = a.pi[kn * M + m]; g0_nx = a.gf[0][kn]; g1_nx = a.gf[1][kn]; cc_nx = a.class_counts[kn];
+            load_row<VEC>(nx, a.mu, a.var, ((size_t)kn * M + m) * D, lane);             // in flight during this class
+        }
+        const size_t off = ((size_t)k * M + m) * D;
+        double ld, mh, mh1 = 0.0;
+        row_logdet_maha<VEC, true>(r, s_x[0], s_x[1], eps, lane, ld, mh, mh1);        // log-det, query and first-fit distances
+        {   // predict on the state before any fit (dota_mixture.py:250-258)
+            const float ll = (float)(-0.5 * (ld + mh));
+            __syncthreads();
+            if (lane == 0) s_j[m] = logf(pi_km + 1e-10f) + ll;
+            __syncthreads();
+            if (m == 0) {                                                               // wave-uniform
+                const float sc = lse_modes_wave(s_j, M, lane);
+                if (lane == 0) a.scores[k] = sc;
+            }
+        }
+#pragma unroll 1
+        for (int f = 0; f < 2; ++f) {                                                   // fits :162-234, B = 1
+            const float* X = s_x[1 + f];
+            const float gk = f ? g1 : g0;
+            if (f > 0) { double unused; row_logdet_maha<VEC, false>(r, X, X, eps, lane, ld, mh1, unused); }   // var changed
+            const float logpi = logf(pi_km + 1e-10f);
+            __syncthreads();
+            if (lane == 0) s_j[m] = logpi + (float)(-0.5 * (ld + mh1));
+            __syncthreads();
+            const float lse = lse_modes_wave(s_j, M, lane);
+            const float g = gk * expf(s_j[m] - lse);                                   // :183-187
+            const float sum_gamma = g;                                                  // :190
+            const float c_new = c_km + sum_gamma;                                       // :196
+            const float den = c_new + 1e-10f;
+            const float rden = __builtin_amdgcn_rcpf(den);
+            const float4* px = reinterpret_cast<const float4*>(X);
+#define UA_UPD1(F)                                                                                    \
+            {                                                                                         \
+                const float mo = r.mu[v].F, vo = r.var[v].F;                                          \
+                const float w1 = g * xv.F, w2 = g * (xv.F * xv.F);  /* :202,:213-214; 0 + g*x of the batched sum dropped (differs for -0 only) */ \
+                const float mn = div_r(c_km * mo + w1, den, rden);                     /* :205-206 */ \
+                const float sq = (w2 + (-2.0f * mo) * w1) + sum_gamma * (mo * mo);     /* :215-217 */ \
+                const float vn = div_r(c_km * vo + sq, den, rden);                     /* :219-220 */ \
+                r.mu[v].F = mn; r.var[v].F = fmaxf(vn, 1e-8f);                         /* :223     */ \
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float4 xv = px[v * 64 + lane];
+                UA_UPD1(x) UA_UPD1(y) UA_UPD1(z) UA_UPD1(w)
+            }
+#undef UA_UPD1
+            c_km = c_new;
+            __syncthreads();                                                            // readers of s_j / s_c of the previous round are done
+            if (lane == 0) s_c[m] = c_new;
+            __syncthreads();
+            float Ck = 0.f;
+            for (int i = 0; i < M; ++i) Ck += s_c[i];
+            pi_km = c_km / (Ck + 1e-10f);                                               // :229-230
+            cc += gk;                                                                   // :233
+        }
+        store_row<VEC>(r, a.mu, a.var, off, lane);
+        if (lane == 0) { a.c[k * M + m] = c_km; a.pi[k * M + m] = pi_km; }
+        if (threadIdx.x == 0) a.class_counts[k] = cc;
+        if (kn < K) { r = nx; c_km = c_nx; pi_km = pi_nx; g0 = g0_nx; g1 = g1_nx; cc = cc_nx; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward of the log-likelihood w.r.t. x: grad_x[b,d] = sum_{k,m} w[b,k,m] * (mu-x)/v.
 // grid (B, D/256), block 256: thread = one feature d, loop over the K*M rows (coalesced 1 KiB
 // row segments, state served from L2 / Infinity Cache).
@@ -287,7 +442,7 @@ gmm_prepare_kernel(const float* __restrict__ var, const float* __restrict__ pi, 
     for (int v = 0; v < VEC; ++v) {
         const float4 a = pv[v * 64 + lane];
         const float x = reg_var(a.x, eps), y = reg_var(a.y, eps), z = reg_var(a.z, eps), w = reg_var(a.w, eps);
-        acc += (double)logf(x) + (double)logf(y) + (double)logf(z) + (double)logf(w);
+        acc += (double)log_normal(x) + (double)log_normal(y) + (double)log_normal(z) + (double)log_normal(w);
         po[v * 64 + lane] = make_float4(1.0f / x, 1.0f / y, 1.0f / z, 1.0f / w);
     }
     acc = wave_sum(acc);
@@ -695,7 +850,17 @@ extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, flo
     a.xq = xq; a.nq = 1; a.round_q = xq_round_fp16; a.scores = scores;
     a.nfit = 2; a.xf[0] = x1; a.xf[1] = x2; a.gf[0] = gamma_class; a.gf[1] = gamma_class; a.bf[0] = 1; a.bf[1] = 1;
     a.K = K; a.M = M; a.eps = eps;
-    return launch_step(a, D, ua::as_stream(stream));
+    if (D > 1024) return launch_step(a, D, ua::as_stream(stream));       // two classes' rows do not fit the register budget
+    // persistent form: at most one workgroup per CU and round-robin classes, so every CU streams its next class
+    // while it computes the current one
+    return dispatch_vec(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        if constexpr (VEC <= 4) {
+            hipLaunchKernelGGL(gmm_step1_kernel<VEC>, dim3(K < 256 ? K : 256), dim3(M * 64), 0, ua::as_stream(stream), a);
+            UA_LAUNCH_CHECK();
+        }
+        return UA_OK;
+    });
 }
 
 extern "C" int ua_gmm_prepare_alignment(const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
