@@ -304,8 +304,11 @@ template <int VEC>
 __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     constexpr int D = 256 * VEC;
     __shared__ __attribute__((aligned(16))) float s_x[3][D];     // query (fp16-rounded if asked), sample, augmented sample
-    __shared__ float s_j[kMaxModes];
-    __shared__ float s_c[kMaxModes];
+    // one LDS slot per exchange of a class (query scores, two E-steps, two count sums): a slot written in class k+1 was last
+    // read several barriers earlier, so only the barrier between a slot's write and its reads is needed (5 per class, not 10)
+    __shared__ float s_jq[kMaxModes];
+    __shared__ float s_jf[2][kMaxModes];
+    __shared__ float s_cf[2][kMaxModes];
     const int m = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int M = a.M, K = a.K;
     const float eps = a.eps;
@@ -340,11 +343,10 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
         row_logdet_maha<VEC, true>(r, s_x[0], s_x[1], eps, lane, ld, mh, mh1);        // log-det, query and first-fit distances
         {   // predict on the state before any fit (dota_mixture.py:250-258)
             const float ll = (float)(-0.5 * (ld + mh));
-            __syncthreads();
-            if (lane == 0) s_j[m] = logf(pi_km + 1e-10f) + ll;
+            if (lane == 0) s_jq[m] = logf(pi_km + 1e-10f) + ll;
             __syncthreads();
             if (m == 0) {                                                               // wave-uniform
-                const float sc = lse_modes_wave(s_j, M, lane);
+                const float sc = lse_modes_wave(s_jq, M, lane);
                 if (lane == 0) a.scores[k] = sc;
             }
         }
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             const float gk = f ? g1 : g0;
             if (f > 0) { double unused; row_logdet_maha<VEC, false>(r, X, X, eps, lane, ld, mh1, unused); }   // var changed
             const float logpi = logf(pi_km + 1e-10f);
-            __syncthreads();
+            float* s_j = s_jf[f];
             if (lane == 0) s_j[m] = logpi + (float)(-0.5 * (ld + mh1));
             __syncthreads();
             const float lse = lse_modes_wave(s_j, M, lane);
@@ -380,11 +382,10 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             }
 #undef UA_UPD1
             c_km = c_new;
-            __syncthreads();                                                            // readers of s_j / s_c of the previous round are done
-            if (lane == 0) s_c[m] = c_new;
+            if (lane == 0) s_cf[f][m] = c_new;
             __syncthreads();
             float Ck = 0.f;
-            for (int i = 0; i < M; ++i) Ck += s_c[i];
+            for (int i = 0; i < M; ++i) Ck += s_cf[f][i];
             pi_km = c_km / (Ck + 1e-10f);                                               // :229-230
             cc += gk;                                                                   // :233
         }
