@@ -77,22 +77,29 @@ def host_cores():
     return max(1, min(n, cap))
 
 
+def _pmc_table():
+    """Per-kernel counters of the committed PMC passes (newest first): profiles/r01_h_pmc.json, r01_f_pmc.json, r01_pmc_traffic.json."""
+    out = {}
+    for name in ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            out.update(d.get('kernels', d))
+        except Exception:
+            pass
+    return out
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        return d['kernels'][kernel]['traffic_bytes']
-    except Exception:
-        return None
+    """HBM bytes per launch from the committed PMC passes, or None."""
+    return _pmc_table().get(kernel, {}).get('traffic_bytes')
 
 
 def pmc_probe(kernel):
-    """Counters of the committed PMC passes for one kernel (profiles/r01_f_pmc.json; probe shape in DESIGN.md section 7), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_f_pmc.json')))[kernel]
-        return {k: d[k] for k in ('us_per_launch_under_pmc', 'traffic_bytes', 'mfma_busy_frac', 'effective_clock_GHz', 'l2_hit_rate') if k in d}
-    except Exception:
+    """Counters of the committed PMC passes for one kernel (probe shape in DESIGN.md section 7), or None."""
+    d = _pmc_table().get(kernel)
+    if not d:
         return None
+    return {k: d[k] for k in ('us_per_launch_under_pmc', 'traffic_bytes', 'mfma_busy_frac', 'effective_clock_GHz', 'l2_hit_rate') if k in d}
 
 
 def similarity_roofline(dev):
@@ -129,7 +136,7 @@ def similarity_roofline(dev):
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                      'frac': round(gbs / PEAK_HBM_GBS, 4),
-                     'traffic': pmc_traffic('gmm_loglik_kernel<4>' if name == 'predict' else 'gmm_step_kernel<4>'), 'bytes_per_launch': nbytes,
+                     'traffic': pmc_traffic('gmm_loglik_kernel<4>' if name == 'predict' else 'gmm_step1_kernel<4>'), 'bytes_per_launch': nbytes,
                      'ms_per_launch': round(ms, 4), 'shape': {'K': K, 'M': M, 'D': D, 'dtype': 'f32'}}
     return out
 
