@@ -213,8 +213,13 @@ def main():
         eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
                         chunk=n_global, device=dev, overlap=a.overlap)
 
+        by_stream = world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'streams'
+
         def step(i):
-            s = slice(i * n_global, (i + 1) * n_global)
+            if by_stream:        # every rank adapts on its own stream (the reference's 15 corruption streams are independent units)
+                s = slice((i * world + rank) * n_local, (i * world + rank + 1) * n_local)
+            else:
+                s = slice(i * n_global, (i + 1) * n_global)
             return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
 
         log(f'[{precision}] model + stream resident; warm-up')
@@ -286,6 +291,8 @@ def main():
                    'replay_overlap': bool(a.overlap),
                    'parallelism': (f'sample-sharded encoder x{world}, in-order cache replay on rank 0 (its encoder share reduced to balance), '
                                    f'1 all_gather/step' if world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'owner' else
+                                   f'{world} independent adaptation streams, one per GPU (the reference rebuilds all state per corruption stream); '
+                                   f'no collective on the data path' if world > 1 and os.environ.get('UA_REPLAY_MODE') == 'streams' else
                                    f'sample-sharded encoder AND cache replay x{world}; 1 all_gather of sufficient-statistic deltas/step '
                                    f'(NOT exact: E-steps see a state up to one step stale)' if world > 1 and os.environ.get('UA_REPLAY_MODE') == 'delta' else
                                    f'sample-sharded encoder x{world}, replicated in-order cache replay, 1 all_gather/step' if world > 1 else

@@ -143,18 +143,18 @@ def _driver_worker(rank, world, port, root, mode):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import uni_adapter_amd  # noqa: F401
-    res = _drive(root, f'run_{mode}_r{rank}')
+    res = _drive(root, f'run_{mode}_r{rank}', 'gaussian,lidar,impulse' if mode == 'streams' else 'gaussian')
     torch.save(res, os.path.join(root, f'res_{mode}_r{rank}.pt'))
     dist.destroy_process_group()
 
 
-def _drive(root, name):
+def _drive(root, name, corruption='gaussian'):
     from uni_adapter_amd import synthetic
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
     from uni_adapter_amd.main_test_time import parse_args, run
     sd = synthetic.uni3d_state_dict(3, trans_dim=128, embed_dim=256, depth=1, device='cuda')
     model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
-    a = parse_args(['--myroot', root, '--dataset_name', 'scanobject', '--corruption', 'gaussian', '--mode-M', '2',
+    a = parse_args(['--myroot', root, '--dataset_name', 'scanobject', '--corruption', corruption, '--mode-M', '2',
                     '--precomputed-text-features', os.path.join(root, 'text.pt'), '--output-dir', os.path.join(root, 'out'),
                     '--name', name, '--chunk-size', '5'])
     return run(a, model=model)
@@ -180,3 +180,27 @@ def test_driver_two_ranks_equals_single_process(tmp_path, mode):
     mp.spawn(_driver_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(os.path.join(tmp_path, f'res_{mode}_r{r}.pt'), weights_only=True) == want
+
+
+@pytest.mark.gpu
+def test_driver_deals_corruption_streams_to_ranks(tmp_path):
+    """--replay-mode streams: the corruption streams are independent units (state rebuilt per corruption), rank r takes streams
+    r, r+W, ...; no collective on the data path, results merged at the end - every rank reports all streams, with the
+    single-process numbers (3 streams on 2 ranks: uneven deal)."""
+    import socket
+    import torch.multiprocessing as mp
+    from uni_adapter_amd import synthetic
+    K, n = 15, 10
+    g = np.random.default_rng(3)
+    for corr in ('gaussian', 'lidar', 'impulse'):
+        pts = g.standard_normal((n, 1024, 3)).astype(np.float32)
+        pts /= np.linalg.norm(pts, axis=-1).max(axis=1)[:, None, None]
+        np.save(os.path.join(tmp_path, f'data_{corr}_5.npy'), pts)
+    np.save(os.path.join(tmp_path, 'label.npy'), g.integers(0, K, size=(n, 1)))
+    torch.save(synthetic.text_bank(K, 256, seed=4), os.path.join(tmp_path, 'text.pt'))
+    want = _drive(str(tmp_path), 'single', 'gaussian,lidar,impulse')
+    assert set(want) == {'gaussian', 'lidar', 'impulse'}
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_driver_worker, args=(2, port, str(tmp_path), 'streams'), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(os.path.join(tmp_path, f'res_streams_r{r}.pt'), weights_only=True) == want

@@ -154,8 +154,12 @@ class TtaEngine:
         # where the sequential cache replay runs when W > 1 (stream.py): 'owner' = rank 0 only, with a
         # smaller encoder share for rank 0; 'replicated' = every rank replays everything
         self.replay_mode = replay_mode or os.environ.get('UA_REPLAY_MODE', 'owner')
-        if self.replay_mode not in ('owner', 'replicated', 'delta', 'class'):
-            raise ValueError(f"replay_mode must be 'owner', 'replicated', 'class' or 'delta', got {self.replay_mode!r}")
+        if self.replay_mode not in ('owner', 'replicated', 'delta', 'class', 'streams'):
+            raise ValueError(f"replay_mode must be 'owner', 'replicated', 'class', 'delta' or 'streams', got {self.replay_mode!r}")
+        if self.replay_mode == 'streams':
+            # every rank adapts on its OWN stream (the driver deals whole corruption streams to ranks: their states are
+            # independent, Uni_Adapter.py:336-352): this engine is a single-process engine whatever the job size
+            self.world, self.rank = 1, 0
         # 'class' (exact, for large K): features are gathered as in 'replicated', but rank r keeps and
         # updates only classes [r*per, (r+1)*per) of the GMM state; one small all_gather per SAMPLE re-assembles the scores
         self.class_mode = self.replay_mode == 'class' and self.world > 1

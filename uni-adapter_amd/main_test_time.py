@@ -56,8 +56,9 @@ def parse_args(argv=None):
     p.add_argument('--chunk-size', type=int, default=16, help='samples encoded per batch (the cache replay stays in stream order)')
     p.add_argument('--gemm-precision', type=str, default='split', choices=['split', 'f32'])
     p.add_argument('--mmap', action='store_true', help='memory-map the corruption .npy instead of reading it')
-    p.add_argument('--replay-mode', type=str, default=None, choices=['owner', 'replicated', 'class', 'delta'],
-                   help='multi-GPU placement of the cache replay (uni_adapter_amd/stream.py); default owner, or UA_REPLAY_MODE')
+    p.add_argument('--replay-mode', type=str, default=None, choices=['owner', 'replicated', 'class', 'delta', 'streams'],
+                   help='multi-GPU placement of the cache replay (uni_adapter_amd/stream.py); default owner, or UA_REPLAY_MODE. '
+                        "'streams': whole corruption streams are dealt to the ranks (independent states, no collective on the data path)")
     args = p.parse_args(argv)
     if args.replay_mode:
         os.environ['UA_REPLAY_MODE'] = args.replay_mode
@@ -83,7 +84,16 @@ def run(args, model=None):
         model = load_point_encoder(args, device=args.device)
     hp = get_hyperparams(args.dataset_name)                                                       # main_test-time.py:42-43
     logging.info(f'Hyperparameters: {hp}')
-    corruptions = CORRUPTIONS if args.corruption == 'all' else [args.corruption]
+    corruptions = CORRUPTIONS if args.corruption == 'all' else [c for c in args.corruption.split(',') if c]
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size() if dist_on else 1
+    rank = torch.distributed.get_rank() if dist_on else 0
+    by_stream = world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'streams'
+    if by_stream:
+        # the reference rebuilds all adaptation state per corruption (Uni_Adapter.py:336-352): the 15 streams are independent
+        # units, so rank r takes streams r, r+W, ... whole - exact, and no collective until the results are merged
+        corruptions = corruptions[rank::world]
+        logging.info(f'rank {rank} of {world}: corruption streams {corruptions}')
     results = {}
     for corr in corruptions:
         args.corruption = corr
@@ -94,6 +104,10 @@ def run(args, model=None):
         result = test_zeroshot_3d_core(test_loader=loader, validate_dataset_name=args.validate_dataset_name, model=model,
                                        clip_model=None, tokenizer=None, args=args, hp=hp)
         results[corr] = result['acc1']
+    if by_stream:
+        parts = [None] * world
+        torch.distributed.all_gather_object(parts, results)
+        results = {k: v for part in parts for k, v in part.items()}
     logging.info(f'Summary of Results: {results}')
     logging.info(f'Average Top-1: {np.mean(list(results.values())):.3f}')
     return results

@@ -31,6 +31,9 @@ All three give results identical to the single-process stream.
     it scales like the encoder, but E-steps inside a step see a state that is up to one step stale: results differ from
     the sequential reference and are checked against the oracle's emulation of the same rule, never used for the parity claim.
 
+  * 'streams' (driver / bench option): nothing is sharded inside a stream - the reference's corruption streams are independent
+    (all state is rebuilt per corruption), so whole streams are dealt to the ranks and every rank runs the single-GPU pipeline.
+
 Device-agnostic on purpose (no HIP calls), so the N>1 logic is covered by world_size-2 gloo tests.
 """
 import torch
