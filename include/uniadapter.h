@@ -75,6 +75,14 @@ int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_c
                       const float* gamma_class, float* scores,
                       int32_t K, int32_t M, int32_t D, float eps, void* stream);
 
+/* ua_gmm_step_fused followed by ua_gmm_prepare_alignment on the updated state, in the same launch (the rows are still in
+ * registers): inv_var (K,M,D) and row_const (K,M) as ua_gmm_prepare_alignment writes them, bit for bit.  Used by the
+ * composite replay when residual learning follows the cache step (Uni_Adapter.py:430 -> :444).                          */
+int ua_gmm_step_fused_prepare(float* mu, float* var, float* pi, float* c, float* class_counts,
+                              const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                              const float* gamma_class, float* scores,
+                              int32_t K, int32_t M, int32_t D, float eps, float* inv_var, float* row_const, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Zero-shot logits and fusion (Uni_Adapter.py)
  * ------------------------------------------------------------------------------------------ */

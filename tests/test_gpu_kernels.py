@@ -143,6 +143,17 @@ def test_stream_step_kernel_is_bit_identical_to_the_generic_one(ua, K, M, D):
         assert torch.equal(sa, sb), it
         for a, b in zip(A, B):
             assert torch.equal(a, b), it
+    # the variant that also emits the residual loop's per-sample constants == step followed by ua_gmm_prepare_alignment
+    x1d, x2d, pd = dev(x1), dev(x2), dev(prob)
+    iv_a, rc_a = torch.empty(K, M, D, device='cuda'), torch.empty(K, M, device='cuda')
+    iv_b, rc_b = torch.empty(K, M, D, device='cuda'), torch.empty(K, M, device='cuda')
+    ua.call('ua_gmm_step_fused_prepare', *(ua.ptr(t) for t in A), ua.ptr(x1d), 1, ua.ptr(x1d), ua.ptr(x2d), ua.ptr(pd), ua.ptr(sa), K, M, D, 1e-4,
+            ua.ptr(iv_a), ua.ptr(rc_a), ua.stream_ptr())
+    ua.call('ua_gmm_step_fused', *(ua.ptr(t) for t in B), ua.ptr(x1d), 1, ua.ptr(x1d), ua.ptr(x2d), ua.ptr(pd), ua.ptr(sb), K, M, D, 1e-4, ua.stream_ptr())
+    ua.call('ua_gmm_prepare_alignment', ua.ptr(B[1]), ua.ptr(B[2]), K, M, D, 1e-4, ua.ptr(iv_b), ua.ptr(rc_b), ua.stream_ptr())
+    assert torch.equal(sa, sb) and torch.equal(iv_a, iv_b) and torch.equal(rc_a, rc_b)
+    for a, b in zip(A, B):
+        assert torch.equal(a, b)
 
 
 def test_predict_is_invariant_to_mode_permutation(ua):

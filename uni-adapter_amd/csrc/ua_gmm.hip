@@ -200,6 +200,7 @@ struct StepArgs {
     const float* xq; int nq; int round_q; float* scores;
     const float* xf[2]; const float* gf[2]; int bf[2]; int nfit;
     int K, M; float eps;
+    float* inv_var; float* row_const;       // gmm_step1_kernel only: also emit what gmm_prepare_kernel would compute from the new state
 };
 
 template <int VEC>
@@ -392,6 +393,18 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
         store_row<VEC>(r, a.mu, a.var, off, lane);
         if (lane == 0) { a.c[k * M + m] = c_km; a.pi[k * M + m] = pi_km; }
         if (threadIdx.x == 0) a.class_counts[k] = cc;
+        if (a.inv_var) {                                   // gmm_prepare_kernel on the rows still in registers (same expressions)
+            float4* po = reinterpret_cast<float4*>(a.inv_var + off);
+            double acc = 0.0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float x = reg_var(r.var[v].x, eps), y = reg_var(r.var[v].y, eps), z = reg_var(r.var[v].z, eps), w = reg_var(r.var[v].w, eps);
+                acc += (double)log_normal(x) + (double)log_normal(y) + (double)log_normal(z) + (double)log_normal(w);
+                po[v * 64 + lane] = make_float4(1.0f / x, 1.0f / y, 1.0f / z, 1.0f / w);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) a.row_const[k * M + m] = (float)((double)logf(pi_km + 1e-10f) - 0.5 * acc);
+        }
         if (kn < K) { r = nx; c_km = c_nx; pi_km = pi_nx; g0 = g0_nx; g1 = g1_nx; cc = cc_nx; }
     }
 }
@@ -838,10 +851,10 @@ extern "C" int ua_gmm_fit(float* mu, float* var, float* pi, float* c, float* cla
     return launch_step(a, D, ua::as_stream(stream));
 }
 
-extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_counts,
-                                 const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
-                                 const float* gamma_class, float* scores,
-                                 int32_t K, int32_t M, int32_t D, float eps, void* stream) {
+static int step_fused_impl(float* mu, float* var, float* pi, float* c, float* class_counts,
+                           const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                           const float* gamma_class, float* scores,
+                           int32_t K, int32_t M, int32_t D, float eps, float* inv_var, float* row_const, void* stream) {
     UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(c); UA_CHECK_PTR(class_counts);
     UA_CHECK_PTR(xq); UA_CHECK_PTR(x1); UA_CHECK_PTR(x2); UA_CHECK_PTR(gamma_class); UA_CHECK_PTR(scores);
     UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(var); UA_CHECK_ALIGN16(xq); UA_CHECK_ALIGN16(x1); UA_CHECK_ALIGN16(x2);
@@ -851,7 +864,11 @@ extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, flo
     a.xq = xq; a.nq = 1; a.round_q = xq_round_fp16; a.scores = scores;
     a.nfit = 2; a.xf[0] = x1; a.xf[1] = x2; a.gf[0] = gamma_class; a.gf[1] = gamma_class; a.bf[0] = 1; a.bf[1] = 1;
     a.K = K; a.M = M; a.eps = eps;
-    if (D > 1024) return launch_step(a, D, ua::as_stream(stream));       // two classes' rows do not fit the register budget
+    if (D > 1024) {                                                      // two classes' rows do not fit the register budget
+        if (int e = launch_step(a, D, ua::as_stream(stream))) return e;
+        return inv_var ? ua_gmm_prepare_alignment(var, pi, K, M, D, eps, inv_var, row_const, stream) : UA_OK;
+    }
+    a.inv_var = inv_var; a.row_const = row_const;
     // persistent form: at most one workgroup per CU and round-robin classes, so every CU streams its next class
     // while it computes the current one
     return dispatch_vec(D, [&](auto vec) {
@@ -862,6 +879,21 @@ extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, flo
         }
         return UA_OK;
     });
+}
+
+extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_counts,
+                                 const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                                 const float* gamma_class, float* scores,
+                                 int32_t K, int32_t M, int32_t D, float eps, void* stream) {
+    return step_fused_impl(mu, var, pi, c, class_counts, xq, xq_round_fp16, x1, x2, gamma_class, scores, K, M, D, eps, nullptr, nullptr, stream);
+}
+
+extern "C" int ua_gmm_step_fused_prepare(float* mu, float* var, float* pi, float* c, float* class_counts,
+                                         const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,
+                                         const float* gamma_class, float* scores,
+                                         int32_t K, int32_t M, int32_t D, float eps, float* inv_var, float* row_const, void* stream) {
+    UA_CHECK_PTR(inv_var); UA_CHECK_PTR(row_const); UA_CHECK_ALIGN16(inv_var);
+    return step_fused_impl(mu, var, pi, c, class_counts, xq, xq_round_fp16, x1, x2, gamma_class, scores, K, M, D, eps, inv_var, row_const, stream);
 }
 
 extern "C" int ua_gmm_prepare_alignment(const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,

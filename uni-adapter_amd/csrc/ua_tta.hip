@@ -24,10 +24,13 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
         int rc;
         if ((rc = ua_clip_logits_pair(f, fa, text, K, D, s->logit_scale, s->fhat, s->faug, s->clip_logits, s->prob,
                                       stream))) return rc;               // :406, :424, :429
-        if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
-                                    s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
-        if (s->res_learning && sample_index0 + j > 0) {                         // :444-476
-            if ((rc = ua_gmm_prepare_alignment(s->var, s->pi, K, M, D, s->eps, s->inv_var, s->row_const, stream))) return rc;
+        const bool learn = s->res_learning && sample_index0 + j > 0;
+        if (learn) {   // cache step + the per-sample constants of the residual loop (1/v, row constants) in one launch
+            if ((rc = ua_gmm_step_fused_prepare(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
+                                                s->prob, s->dota_scores, K, M, D, s->eps, s->inv_var, s->row_const, stream))) return rc;
+        } else if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
+                                           s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
+        if (learn) {                                                            // :444-476
             for (int it = 0; it < s->res_steps; ++it) {
                 if ((rc = ua_align_forward(s->mu, s->inv_var, s->row_const, s->e, K, K, M, D, s->L, s->joint, stream))) return rc;
                 ++adam_step;

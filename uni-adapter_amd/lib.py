@@ -51,6 +51,7 @@ SIGNATURES = {
     'ua_gmm_loglik_bwd': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p, _p],
     'ua_gmm_fit': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _f, _p],
     'ua_gmm_step_fused': [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p],
+    'ua_gmm_step_fused_prepare': [_p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p],
     'ua_clip_logits': [_p, _p, _i32, _i32, _f, _i32, _p, _p, _p, _p, _p, _p],
     'ua_clip_logits_pair': [_p, _p, _p, _i32, _i32, _f, _p, _p, _p, _p, _p],
     'ua_fuse_logits': [_p, _p, _p, _i32, _i32, _f, _f, _i32, _p, _p, _p, _p, _p],
