@@ -279,3 +279,33 @@ def test_class_sharded_replay_over_gloo_equals_single_process(tmp_path, world):
         assert torch.equal(got['final'].argmax(1), want.argmax(1))
         k0, k1 = got['k']
         assert torch.equal(got['mu'], s.st.mu[k0:k1])
+
+
+def test_share_rules_partition_every_step():
+    """Host-side sharding rules over a sweep of step sizes, world sizes and cost ratios: the per-rank blocks are a partition
+    of the step in stream order; rank 0's share shrinks with rho and never exceeds the even share; class slices of the
+    class-sharded replay tile [0, K) without overlap for any K and W."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import shard_block, shard_counts, shard_indices
+    from oracle import ref_cpu as O
+    for world in (1, 2, 3, 4, 7, 8):
+        for n in (0, 1, 2, 5, 31, 62, 124, 248, 255):
+            for rho in (0.0, 0.1, 0.15, 0.3, 1.0):
+                counts = shard_counts(n, world, rho)
+                assert len(counts) == world and sum(counts) == n and min(counts) >= 0
+                if world > 1:
+                    assert counts[0] <= -(-n // world)
+                    assert max(counts[1:]) - min(counts[1:]) <= 1
+                got = torch.cat([shard_block(n, r, world, rho) for r in range(world)])
+                assert torch.equal(got, torch.arange(n))
+            assert shard_counts(n, world, 0.0) == O.even_counts(n, world)
+            strided = torch.cat([shard_indices(n, r, world) for r in range(world)]).sort().values
+            assert torch.equal(strided, torch.arange(n))
+    for world in (2, 3, 8, 16):
+        for K in (1, 5, 15, 40, 55, 1156, 4096):
+            per = -(-K // world)
+            edges = [(min(r * per, K), min(min(r * per, K) + per, K)) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == K
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
