@@ -360,9 +360,12 @@ int ua_vec_merge(const float* base, const float* deltas, int32_t W, int64_t stri
  * (clip logits: computed on every rank) and mean(c) at Uni_Adapter.py:491.  per = ceil(K/W) classes per rank.
  * ua_class_shard_pack: out (per+2 floats) = [this rank's K_local <= per scores, zero padded | fp64 sum of its c slice as a
  *   (hi, lo) float pair].
- * ua_fuse_logits_sharded: ua_fuse_logits from the W gathered buffers (rank order); dota_out (K) optional.               */
+ * ua_fuse_logits_sharded: ua_fuse_logits for n samples from the W gathered buffers - gathered is (W, n, per+2), rank order,
+ *   i.e. the all_gather of every rank's (n, per+2) pack buffers of a chunk; clip_logits / final_logits / dota_out (optional)
+ *   are (n,K), target / rank / pred (n).  With residual learning off nothing the fusion produces feeds back into the state
+ *   (Uni_Adapter.py:417,430,491), so ONE collective per chunk carries all n score slices.                                */
 int ua_class_shard_pack(const float* scores, const float* c, int32_t K_local, int32_t M, int32_t per, float* out, void* stream);
-int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t per, int32_t K, int32_t M,
+int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t n, int32_t per, int32_t K, int32_t M,
                            float rho, float eta, int32_t batch, const int32_t* target, float* final_logits, int32_t* rank,
                            int32_t* pred, float* dota_out, void* stream);
 

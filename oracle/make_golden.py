@@ -3,11 +3,14 @@
 
 TEST INFRASTRUCTURE ONLY - run in the build container (the GPU box has no /root/reference):
 
-    python oracle/make_golden.py            # writes tests/golden/
+    python oracle/make_golden.py [--skip-long | --only-long]     # writes tests/golden/
+                                        (the g12 long streams take ~20 minutes; --only-long regenerates just those)
 
 What executes reference code here (nothing is copied into the repo; only inputs/outputs are
 stored):
-  * `dota_mixture.DOTA_mix` is imported as a module (it needs only torch).
+  * `dota_mixture.py` (it needs only torch) and `utils/math_utils.py` are executed from their SOURCE TEXT
+    (`compile(open(path).read())` into a fresh module object): Python's bytecode cache is bypassed, so a stale
+    `.pyc` shipped in the reference is never executed and nothing is written under /root/reference.
   * `Uni_Adapter.py` cannot be imported (needs `clip`, `open_clip`), so the pure functions
     `softmax_entropy`, `get_logits_wrapper`, `compute_text_alignment_loss` and the
     `--use-mode-dota` statements of the per-sample loop body (Uni_Adapter.py:388-521) are located
@@ -24,6 +27,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -35,6 +40,15 @@ OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import ref_cpu as O  # noqa: E402  (weights helper only)
+
+
+def _load_source_module(name, path):
+    """Execute a reference file from its source text into a fresh module (no import machinery, no bytecode cache)."""
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    with open(path) as f:
+        exec(compile(f.read(), path, 'exec'), mod.__dict__)
+    return mod
 
 
 def _tree(path):
@@ -121,10 +135,25 @@ def make_features(text, n, seed, noise=0.05, aug_noise=0.02):
     return f.contiguous(), fa.contiguous(), labels
 
 
-def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture):
+def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture, dtype=torch.float32):
+    """dtype=torch.float64 runs the SAME reference statements in double precision: the state is initialised in fp32 (so
+    that every arithmetic starts from identical numbers) and cast to double, and `Tensor.float()` - which the reference
+    calls on its inputs (dota_mixture.py:170-171,250; Uni_Adapter.py:394) - is mapped to `Tensor.double()` for the run."""
     K, D = text.shape
     cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
     f, fa, labels = make_features(text, n_steps, seed)
+    if dtype == torch.float64:
+        orig_float = torch.Tensor.float
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+        try:
+            return _run_stream(text, M, n_steps, f, fa, labels, cfg, ua_ns, loop_code, dota_mixture, dtype)
+        finally:
+            torch.Tensor.float = orig_float
+    return _run_stream(text, M, n_steps, f, fa, labels, cfg, ua_ns, loop_code, dota_mixture, dtype)
+
+
+def _run_stream(text, M, n_steps, f, fa, labels, cfg, ua_ns, loop_code, dota_mixture, dtype, progress=None):
+    K, D = text.shape
     args = types.SimpleNamespace(vlm3d='uni3d', use_dota=False, use_mode_dota=True, res_learning=True,
                                  print_freq=10 ** 9, device='cpu', use_gmm_dota=False)
     model = Feeder()
@@ -132,6 +161,11 @@ def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture):
     text_features_initial = text_features.clone().detach()
     mdl = dota_mixture.DOTA_mix(cfg, D, K, text_features_initial.T, num_modes=M)
     mdl.eval()
+    if dtype != torch.float32:
+        for nm in ('mu', 'var', 'pi', 'c', 'class_counts'):
+            setattr(mdl, nm, getattr(mdl, nm).to(dtype))
+        text_features, text_features_initial = text_features.to(dtype), text_features_initial.to(dtype)
+        f, fa = f.to(dtype), fa.to(dtype)
     raw = {}
     orig_predict = mdl.predict
     def predict_spy(x, source_priors=None):
@@ -165,10 +199,13 @@ def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture):
         rec['cmean'].append(float(mdl.c.mean()))
         rec['w'].append(float(ns['dota_weights_val']))
         rec['loss'].append(float(ns['alignment_loss']) if i > 0 else float('nan'))
+        if progress and i % 16 == 0:
+            print(f'[long stream {progress}] step {i}/{n_steps}', flush=True)
         if i in (0, 1, n_steps // 2, n_steps - 1):
             snaps[i] = dict(c=mdl.c.clone(), pi=mdl.pi.clone(), res=text_residuals.detach().clone())
     out = dict(
-        text=text.numpy(), M=np.int64(M), feat=f.numpy(), feat_aug=fa.numpy(), labels=labels.numpy(),
+        text=text.numpy(), M=np.int64(M), feat=f.numpy().astype(np.float32), feat_aug=fa.numpy().astype(np.float32),
+        labels=labels.numpy(),
         clip=torch.stack(rec['clip']).numpy(), dota_raw=torch.stack(rec['dota_raw']).numpy(),
         final=torch.stack(rec['final']).numpy(), pred=np.array(rec['pred'], dtype=np.int64),
         cmean=np.array(rec['cmean']), w=np.array(rec['w']), loss=np.array(rec['loss']),
@@ -190,18 +227,13 @@ def run_stream(text, M, n_steps, seed, ua_ns, loop_code, dota_mixture):
     return out, mdl, text_residuals.detach().clone()
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    torch.manual_seed(0)
-    torch.set_num_threads(1)            # fixes CPU reduction order for reproducible fixtures
-    sys.path.insert(0, REF)
-    import dota_mixture                                                     # reference module
+def _reference_pieces():
+    dota_mixture = _load_source_module('ref_dota_mixture', os.path.join(REF, 'dota_mixture.py'))   # reference module
     ua_path = os.path.join(REF, 'Uni_Adapter.py')
     ua_ns = {'torch': torch, 'F': F, 'np': np}
     _exec_defs(ua_path, ['softmax_entropy', 'get_logits_wrapper', 'compute_text_alignment_loss'], ua_ns)
     loop_code = _loop_body_statements(ua_path)
     fusion_code = _fusion_statements(ua_path)
-
     tf = os.path.join(REF, 'precomputed_text_features', 'Uni3D')
     banks = {
         'modelnet40': torch.load(os.path.join(tf, 'text_features_large.pt'), map_location='cpu', weights_only=True),
@@ -209,6 +241,100 @@ def main():
         'shapenet55': torch.load(os.path.join(tf, 'text_features_large_shapenetcorev2.pt'), map_location='cpu', weights_only=True),
     }
     banks = {k: v.float().contiguous() for k, v in banks.items()}
+    return dota_mixture, ua_ns, loop_code, fusion_code, banks
+
+
+# ---- G12: long stream, the reference's loop against ITSELF under other fp32 summation orders and in fp64 -------------
+# Residual learning makes the reference's fp32 trajectory sensitive to rounding (the loss routes a gradient through
+# likelihood_matrix.max(), Uni_Adapter.py:247-248, and Adam's first steps are sign-like).  To pin how far two correct fp32
+# evaluations of the SAME reference statements drift apart over a stream, the loop body is run on one 256-sample stream
+#   a: as is, 1 thread (the arithmetic of the g2 fixtures)      b: the same with 8 threads
+#   c: with the feature dimension permuted (text bank and features; the first 16 coordinates - the ones the
+#      initialisation offsets touch, dota_mixture.py:70-79 - stay in place): mathematically the same stream,
+#      every sum over D associates differently
+#   d: with the class order permuted (rows of the text bank; logits mapped back): every sum over K associates differently
+#   e: in fp64 (see run_stream) - the "truth" the fp32 runs scatter around
+# and per-step final logits / predictions of each are stored.  Tests assert the HIP path against the envelope of a-d.
+LONG = dict(bank='modelnet40', M=8, n=256, seed=14)
+LONG_VARIANTS = ('a', 'b', 'c', 'd', 'e')
+
+
+def long_stream_variant(variant, out_path):
+    dota_mixture, ua_ns, loop_code, _, banks = _reference_pieces()
+    text = banks[LONG['bank']]
+    K, D = text.shape
+    M, n = LONG['M'], LONG['n']
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    f, fa, labels = make_features(text, n, LONG['seed'])
+    torch.set_num_threads(8 if variant == 'b' else 1)
+    g = torch.Generator().manual_seed(1000 + ord(variant))
+    back = None
+    if variant == 'c':
+        perm = torch.cat([torch.arange(16), 16 + torch.randperm(D - 16, generator=g)])
+        text, f, fa = text[:, perm].contiguous(), f[:, perm].contiguous(), fa[:, perm].contiguous()
+    if variant == 'd':
+        q = torch.randperm(K, generator=g)
+        text = text[q].contiguous()
+        back = torch.argsort(q)                                   # class k of the original order sits at row back[k]
+    dtype = torch.float64 if variant == 'e' else torch.float32
+    if dtype == torch.float64:
+        orig_float = torch.Tensor.float
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+    try:
+        out, _, _ = _run_stream(text, M, n, f, fa, labels, cfg, ua_ns, loop_code, dota_mixture, dtype, progress=variant)
+    finally:
+        if dtype == torch.float64:
+            torch.Tensor.float = orig_float
+    final, pred, dz, clip = out['final'], out['pred'], out['dota_raw'], out['clip']
+    if back is not None:
+        final, dz, clip = final[:, back.numpy()], dz[:, back.numpy()], clip[:, back.numpy()]
+        pred = q.numpy()[pred]
+    np.savez_compressed(out_path, final=final, pred=pred.astype(np.int64), dota_raw=dz, clip=clip, w=out['w'], loss=out['loss'])
+
+
+def long_streams():
+    """Runs the five variants as parallel child processes (several minutes each) and merges them into one fixture."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='ua_g12_')
+    procs = {v: subprocess.Popen([sys.executable, os.path.abspath(__file__), '--long-variant', v, os.path.join(tmp, v + '.npz')])
+             for v in LONG_VARIANTS}
+    for v, pr in procs.items():
+        if pr.wait() != 0:
+            raise RuntimeError(f'long-stream variant {v} failed')
+    dota_mixture, ua_ns, loop_code, _, banks = _reference_pieces()
+    text = banks[LONG['bank']]
+    f, fa, labels = make_features(text, LONG['n'], LONG['seed'])
+    out = dict(text=text.numpy(), M=np.int64(LONG['M']), feat=f.numpy(), feat_aug=fa.numpy(), labels=labels.numpy(),
+               variants=np.array(LONG_VARIANTS))
+    for v in LONG_VARIANTS:
+        d = np.load(os.path.join(tmp, v + '.npz'))
+        out['final_' + v] = d['final'] if v == 'e' else d['final'].astype(np.float32)
+        out['pred_' + v] = d['pred']
+        out['dota_raw_' + v] = d['dota_raw'] if v == 'e' else d['dota_raw'].astype(np.float32)
+        if v in ('a', 'e'):
+            out['clip_' + v] = d['clip']
+            out['loss_' + v] = d['loss']
+        if v == 'a':
+            out['w'] = d['w']
+    np.savez_compressed(os.path.join(OUT, 'g12_long_stream_modelnet40.npz'), **out)
+    fa_, fe = out['final_a'].astype(np.float64), out['final_e']
+    for v in LONG_VARIANTS[1:]:
+        dv = np.abs(out['final_' + v].astype(np.float64) - fa_).max(1)
+        print('g12', v, 'vs a: max', dv.max(), 'first step over 1e-3:', int(np.argmax(dv > 1e-3)) if (dv > 1e-3).any() else None,
+              'pred agreement', float((out['pred_' + v] == out['pred_a']).mean()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) >= 4 and sys.argv[1] == '--long-variant':
+        return long_stream_variant(sys.argv[2], sys.argv[3])
+    if '--only-long' in sys.argv:
+        return long_streams()
+    torch.manual_seed(0)
+    torch.set_num_threads(1)            # fixes CPU reduction order for reproducible fixtures
+    dota_mixture, ua_ns, loop_code, fusion_code, banks = _reference_pieces()
+    ua_path = os.path.join(REF, 'Uni_Adapter.py')
 
     # ---- G1/G2: init + full loop-body stream (reference DOTA_mix + loop statements) ----
     for name, M, n, seed in (('modelnet40', 8, 48, 11), ('scanobjectnn', 8, 24, 12), ('shapenet55', 4, 16, 13)):
@@ -397,9 +523,7 @@ def main():
                         Lambda=ref10.Lambda.float().numpy())
     print('g10 dota full covariance', torch.cat(sc10).shape)
     # ---- G11: original cluster cache + graph refinement (Uni_Adapter.py:78-156,541-574; utils/math_utils.py imported as is) ----
-    import importlib.util
-    spec11 = importlib.util.spec_from_file_location('ref_math_utils', os.path.join(REF, 'utils', 'math_utils.py'))
-    mu11 = importlib.util.module_from_spec(spec11); spec11.loader.exec_module(mu11)
+    mu11 = _load_source_module('ref_math_utils', os.path.join(REF, 'utils', 'math_utils.py'))
     ns11 = {'torch': torch, 'F': F, 'np': np, 'math_utils': mu11}
     _exec_defs(os.path.join(REF, 'Uni_Adapter.py'), ['softmax_entropy', 'get_entropy', 'update_cache', 'compute_cache_logits'], ns11)
     K11, D11, n11, cap11 = 6, 256, 40, 3
@@ -429,6 +553,8 @@ def main():
                         threshold=np.float64(0.5), lambda_reg=np.float64(0.11), finals=torch.cat(fin11).numpy(), cache_logits=torch.cat(z211).numpy(),
                         final_keys=keys11.numpy(), final_counts=np.array([it[3] for c in sorted(cache11) for it in cache11[c]], dtype=np.int64))
     print('g11 cluster cache', keys11.shape)
+    if '--skip-long' not in sys.argv:
+        long_streams()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

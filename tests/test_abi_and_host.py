@@ -87,7 +87,7 @@ def test_bad_arguments_return_codes_without_gpu():
     with pytest.raises(RuntimeError, match='invalid argument'):
         lib.call('ua_class_shard_pack', p16, p16, 5, 2, 4, p16, None)
     with pytest.raises(RuntimeError, match='invalid argument'):
-        lib.call('ua_fuse_logits_sharded', p16, p16, 2, 4, 9, 2, 0.02, 0.1, 1, None, p16, None, None, None, None)
+        lib.call('ua_fuse_logits_sharded', p16, p16, 2, 1, 4, 9, 2, 0.02, 0.1, 1, None, p16, None, None, None, None)
     e = lib.GemmEpilogue(); e.rowgroup_add = p16; e.ldg = 64; e.group_rows = 48
     with pytest.raises(RuntimeError, match='envelope'):
         lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 96, 64, 64, ctypes.byref(e), None)

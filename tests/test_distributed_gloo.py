@@ -227,9 +227,9 @@ def test_delta_mode_properties():
         assert (d.s.st.var >= 1e-8).all() and d.s.i == n
 
 
-def _worker_class(rank, world, port, n, out):
-    """'class' mode over gloo: each rank keeps classes [r*per,(r+1)*per) of the oracle state; per sample one gather of
-    (score slice | partial sum of c)."""
+def _worker_class(rank, world, port, n, out, chunk=4):
+    """'class' mode over gloo: each rank keeps classes [r*per,(r+1)*per) of the oracle state and steps it through a whole
+    chunk; ONE gather per chunk of (score slice | partial sum of c after the sample) for all its samples, then the fusion."""
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -244,28 +244,36 @@ def _worker_class(rank, world, port, n, out):
     full = O.gmm_init(text, M, 1e-4, 1e-4)
     st = O.GmmState(full.mu[k0:k1].clone(), full.var[k0:k1].clone(), full.pi[k0:k1].clone(), full.c[k0:k1].clone(),
                     full.class_counts[k0:k1].clone(), full.epsilon)
-    finals = []
-    for j in range(n):
-        f, z, ent, prob, pred = O.clip_logits(feats[j, 0:1], text)                 # all K, on every rank
-        fa = O.clip_logits(feats[j, 1:2], text)[0]
-        fa = fa / fa.norm(dim=-1, keepdim=True)
-        buf = torch.zeros(per + 1, dtype=torch.float64)
-        if k1 > k0:
-            buf[:k1 - k0] = O.gmm_predict(st, f.mean(0)[None].half())[0].double()
-            O.gmm_fit(st, f, prob[:, k0:k1]); O.gmm_fit(st, fa, prob[:, k0:k1])
-            buf[per] = st.c.double().sum()
-        g = gather_deltas(buf, world)                                              # the per-sample collective
-        dz = torch.cat([g[r, :per] for r in range(world)])[:K].float()[None]
-        cmean = (g[:, per].sum() / (K * M)).float()
-        finals.append(O.fuse_logits(z, dz, cmean, 0.02, 0.1))
+    finals, collectives = [], 0
+    for s0 in range(0, n, chunk):
+        nb = min(chunk, n - s0)
+        buf = torch.zeros(nb, per + 1, dtype=torch.float64)
+        zs = []
+        for j in range(nb):
+            f, z, ent, prob, pred = O.clip_logits(feats[s0 + j, 0:1], text)          # all K, on every rank
+            fa = O.clip_logits(feats[s0 + j, 1:2], text)[0]
+            fa = fa / fa.norm(dim=-1, keepdim=True)
+            zs.append(z)
+            if k1 > k0:
+                buf[j, :k1 - k0] = O.gmm_predict(st, f.mean(0)[None].half())[0].double()
+                O.gmm_fit(st, f, prob[:, k0:k1]); O.gmm_fit(st, fa, prob[:, k0:k1])
+                buf[j, per] = st.c.double().sum()
+        g = gather_deltas(buf, world)                                              # the ONE collective of the chunk: (W, nb, per+1)
+        collectives += 1
+        for j in range(nb):
+            dz = torch.cat([g[r, j, :per] for r in range(world)])[:K].float()[None]
+            cmean = (g[:, j, per].sum() / (K * M)).float()
+            finals.append(O.fuse_logits(zs[j], dz, cmean, 0.02, 0.1))
+    assert collectives == -(-n // chunk)
     torch.save({'final': torch.cat(finals), 'mu': st.mu, 'k': (k0, k1)}, out + f'.r{rank}')
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_class_sharded_replay_over_gloo_equals_single_process(tmp_path, world):
-    """N>1 'class' path: the cache step is independent per class, so rank-local slices + one small gather per sample
-    reproduce the single-process stream (K = 5 is not a multiple of W)."""
+    """N>1 'class' path: the cache step is independent per class and (without residual learning) the fusion feeds nothing
+    back into the state, so rank-local slices stepped through a chunk + ONE gather per chunk reproduce the single-process
+    stream (K = 5 is not a multiple of W; the last chunk is ragged)."""
     from oracle import ref_cpu as O
     n = 9
     text, feats = _delta_inputs(n)

@@ -470,7 +470,7 @@ def test_delta_replay_mode_two_processes_match_lockstep(tmp_path):
 @pytest.mark.parametrize('name,world', [('scanobjectnn', 4), ('scanobjectnn', 16), ('modelnet40', 8), ('shapenet55', 3)])
 def test_class_sharded_replay_is_bit_identical_to_one_gpu(golden_dir, name, world):
     """'class' replay mode (exact mode for large K): rank r holds classes [r*per,(r+1)*per) of the state,
-    per sample one (per+2)-float buffer per rank is exchanged.  W engines driven in lock-step in one process (the stacked
+    per CHUNK one (n, per+2) buffer per rank is exchanged.  W engines driven in lock-step in one process (the stacked
     buffers stand in for the all_gather) against ONE engine holding everything: final logits, predictions, accuracy and
     every rank's slice of the state are bit-identical (K not a multiple of W, ranks with no class at all included)."""
     from uni_adapter_amd.Uni_Adapter import TtaEngine
@@ -485,10 +485,11 @@ def test_class_sharded_replay_is_bit_identical_to_one_gpu(golden_dir, name, worl
     engs = [TtaEngine(None, text, cfg, M, res_learning=False, chunk=n, replay_mode='class', emulated_rank=(r, world)) for r in range(world)]
     final = torch.empty(world, n, K, device='cuda'); ranks = torch.empty(world, n, dtype=torch.int32, device='cuda')
     preds = torch.empty(world, n, dtype=torch.int32, device='cuda')
-    for j in range(n):
-        gathered = torch.stack([e.class_local(feats[j, 0:1], feats[j, 1:2]).clone() for e in engs])
+    for s0 in range(0, n, 5):                                                    # chunks of 5, 5, 2: one exchange per chunk
+        s1 = min(n, s0 + 5)
+        gathered = torch.stack([e.class_local_chunk(feats[s0:s1]).clone() for e in engs])
         for r, e in enumerate(engs):
-            e.class_fuse(gathered, tgt[j:j + 1], final[r, j:j + 1], ranks[r, j:j + 1], preds[r, j:j + 1])
+            e.class_fuse_chunk(gathered, tgt[s0:s1], final[r, s0:s1], ranks[r, s0:s1], preds[r, s0:s1])
     torch.cuda.synchronize()
     for r, e in enumerate(engs):
         assert torch.equal(final[r], want[0]) and torch.equal(ranks[r], want[1]) and torch.equal(preds[r], want[2]), r
@@ -500,6 +501,54 @@ def test_class_sharded_replay_is_bit_identical_to_one_gpu(golden_dir, name, worl
     assert sum(e.class_k1 - e.class_k0 for e in engs) == K
     with pytest.raises(ValueError, match='residual learning'):
         TtaEngine(None, text, cfg, M, res_learning=True, replay_mode='class', emulated_rank=(0, 2))
+
+
+@pytest.mark.parametrize('K,M', [(1156, 8), (4096, 16)])
+def test_class_sharded_replay_at_baseline_bank_sizes(K, M):
+    """BASELINE configs[3] (1156 classes, M = 8) and configs[4] (4096 x 16) at D = 1024, W = 8 ranks in lock-step, no residual
+    learning (infeasible at such K in the reference too, SURVEY defect 11): the class-sharded replay (a) equals ONE engine
+    holding the whole state bit for bit and (b) matches the CPU oracle's loop body on the same stream - predictions
+    identical, final logits within 1e-3 (the north-star bar), in fp32 and against the fp64 oracle."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    D, W, n, chunk = 1024, 8, 4, 2
+    g = torch.Generator().manual_seed(100 + K)
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    lab = torch.randint(0, K, (n,), generator=g)
+    scale = 1.0 + 4.0 * torch.rand(n, 1, generator=g)
+    f = (text[lab] + 0.05 * torch.randn(n, D, generator=g)) * scale
+    fa = (f / scale + 0.02 * torch.randn(n, D, generator=g)) * scale
+    feats = torch.stack([f, fa], 1).cuda()
+    tgt = lab.int().cuda()
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    one = TtaEngine(FeatureFeeder(feats), text, cfg, M, res_learning=False, chunk=n)
+    want = one.process_chunk(torch.zeros(n, 8, 3), torch.ones(n, 8, 3), tgt.cpu())
+    engs = [TtaEngine(None, text, cfg, M, res_learning=False, chunk=chunk, replay_mode='class', emulated_rank=(r, W)) for r in range(W)]
+    final = torch.empty(W, n, K, device='cuda'); ranks = torch.empty(W, n, dtype=torch.int32, device='cuda')
+    preds = torch.empty(W, n, dtype=torch.int32, device='cuda')
+    for s0 in range(0, n, chunk):
+        s1 = s0 + chunk
+        gathered = torch.stack([e.class_local_chunk(feats[s0:s1]).clone() for e in engs])          # stands in for the one all_gather
+        for r, e in enumerate(engs):
+            e.class_fuse_chunk(gathered, tgt[s0:s1], final[r, s0:s1], ranks[r, s0:s1], preds[r, s0:s1])
+    torch.cuda.synchronize()
+    for r, e in enumerate(engs):
+        assert torch.equal(final[r], want[0]) and torch.equal(ranks[r], want[1]) and torch.equal(preds[r], want[2]), r
+        k0, k1 = e.class_k0, e.class_k1
+        for a, b in ((e.mode_dota_model.mu, one.mode_dota_model.mu), (e.mode_dota_model.var, one.mode_dota_model.var),
+                     (e.mode_dota_model.c, one.mode_dota_model.c)):
+            assert torch.equal(a[k0:k1], b[k0:k1]), r
+    del engs
+    s32 = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False))
+    s64 = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False), dtype=torch.float64)
+    got = want[0].cpu()
+    for i in range(n):
+        _, _, r32, p32 = s32.step(f[i:i + 1], fa[i:i + 1])
+        _, _, r64, p64 = s64.step(f[i:i + 1].double(), fa[i:i + 1].double())
+        assert int(want[2][i]) == int(r32.argmax()) == int(r64.argmax()), i
+        assert (got[i] - r32[0]).abs().max().item() <= 1e-3, (i, (got[i] - r32[0]).abs().max().item())
+        assert (got[i].double() - r64[0]).abs().max().item() <= 1e-3, (i, (got[i].double() - r64[0]).abs().max().item())
+    np.testing.assert_allclose(one.mode_dota_model.c.cpu().numpy(), s32.st.c.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(one.mode_dota_model.mu.cpu().numpy(), s32.st.mu.numpy(), rtol=1e-5, atol=2e-7)
 
 
 def _class_mode_worker(rank, world, port, out):
@@ -537,7 +586,7 @@ def _run_small_stream_no_res():
 
 
 def test_class_sharded_replay_two_processes(tmp_path):
-    """The real path (sample-sharded encoder, all_gather of features per chunk, all_gather of score slices per sample,
+    """The real path (sample-sharded encoder, all_gather of features per chunk, all_gather of score slices per chunk,
     replay overlapped on the second stream) with 2 ranks sharing cuda:0 equals the single-process stream bit for bit."""
     import socket
     import torch.multiprocessing as mp

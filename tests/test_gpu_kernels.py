@@ -156,6 +156,85 @@ def test_stream_step_kernel_is_bit_identical_to_the_generic_one(ua, K, M, D):
         assert torch.equal(a, b)
 
 
+# BASELINE.json configs[3] (Objaverse-LVIS: 1156 classes, M = 8) and configs[4] (4096 classes x 16 modes), D = 1024
+LARGE_BANKS = [(1156, 8, 1024), (4096, 16, 1024)]
+
+
+def _large_bank(K, M, D, seed, warm=2):
+    """normalize(randn(K,D)) text bank (SURVEY section 8d for configs 4-5), oracle init, `warm` stream samples (two fits each)."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    st = O.gmm_init(text, M, 1e-4, 1e-4)
+    for _ in range(warm):
+        lab = torch.randint(0, K, (1,), generator=g)
+        x = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(1, D, generator=g), dim=1)
+        gam = torch.softmax(100 * x @ text.T, 1)
+        O.gmm_fit(st, x, gam)
+        O.gmm_fit(st, torch.nn.functional.normalize(x + 0.02 * torch.randn(1, D, generator=g), dim=1), gam)
+    return text, st, g
+
+
+@pytest.mark.parametrize('K,M,D', LARGE_BANKS)
+def test_similarity_kernel_at_baseline_bank_sizes(ua, K, M, D):
+    """ua_gmm_loglik (the similarity kernel, dota_mixture.py:236-267) at the sizes of BASELINE configs[3] / configs[4]
+    against the oracle in fp32 and fp64, same bar as the small shapes (2e-3 on raw scores of magnitude 3e3)."""
+    text, st, g = _large_bank(K, M, D, 41)
+    B = 3
+    lab = torch.randint(0, K, (B,), generator=g)
+    x = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+    scores = torch.empty(B, K, device='cuda'); joint = torch.empty(B, K, M, device='cuda')
+    ua.call('ua_gmm_loglik', ua.ptr(dev(st.mu)), ua.ptr(dev(st.var)), ua.ptr(dev(st.pi)), ua.ptr(dev(x)),
+            B, K, M, D, st.epsilon, ua.ptr(scores), ua.ptr(joint), None, ua.stream_ptr())
+    got, gotj = scores.cpu(), joint.cpu()
+    TOL = 2e-3
+    st64 = _as64(st)
+    for b in range(B):                                         # one query at a time: the fp64 oracle holds (1,K,M,D) doubles
+        ref64 = O.gmm_predict(st64, x[b:b + 1].double())
+        ref32 = O.gmm_predict(st, x[b:b + 1])
+        ref_err = (ref32.double() - ref64).abs().max().item()
+        assert (got[b:b + 1].double() - ref64).abs().max().item() <= TOL, (b, K)
+        assert (got[b:b + 1] - ref32).abs().max().item() <= ref_err + TOL
+        assert (gotj[b:b + 1].double() - O.gmm_joint(st64, x[b:b + 1].double())).abs().max().item() <= TOL
+        assert int(got[b].argmax()) == int(ref64.argmax()) == int(lab[b])
+
+
+@pytest.mark.parametrize('K,M,D', LARGE_BANKS)
+def test_fused_cache_step_at_baseline_bank_sizes(ua, K, M, D):
+    """ua_gmm_step_fused (predict + fit + fit in one pass over the state, Uni_Adapter.py:416,417,430) for 4 consecutive
+    stream samples at the configs[3] / configs[4] sizes against the oracle stepping the same samples in fp32 and fp64:
+    scores at the 2e-3 bar, state at the tolerances of the small-shape fit test, count mass conserved."""
+    text, st, g = _large_bank(K, M, D, 43)
+    st64 = _as64(st)
+    T = [dev(t.clone()) for t in (st.mu, st.var, st.pi, st.c, st.class_counts)]
+    for it in range(4):
+        lab = int(torch.randint(0, K, (1,), generator=g))
+        x1 = torch.nn.functional.normalize(text[lab:lab + 1] + 0.05 * torch.randn(1, D, generator=g), dim=1)
+        x2 = torch.nn.functional.normalize(x1 + 0.02 * torch.randn(1, D, generator=g), dim=1)
+        prob = torch.softmax(100 * x1 @ text.T, 1)
+        sc = torch.empty(1, K, device='cuda')
+        ua.call('ua_gmm_step_fused', *(ua.ptr(t) for t in T), ua.ptr(dev(x1)), 1, ua.ptr(dev(x1)), ua.ptr(dev(x2)), ua.ptr(dev(prob)),
+                ua.ptr(sc), K, M, D, 1e-4, ua.stream_ptr())
+        xq = x1.half()
+        ref32 = O.gmm_predict(st, xq); ref64 = O.gmm_predict(st64, xq.double())
+        O.gmm_fit(st, x1, prob); O.gmm_fit(st, x2, prob)
+        O.gmm_fit(st64, x1.double(), prob.double()); O.gmm_fit(st64, x2.double(), prob.double())
+        ref_err = (ref32.double() - ref64).abs().max().item()
+        got = sc.cpu()
+        assert (got.double() - ref64).abs().max().item() <= 2e-3 + ref_err, (it, (got.double() - ref64).abs().max().item(), ref_err)
+        assert int(got.argmax()) == int(ref64.argmax())
+        mu, var, pi, c, cc = (t.cpu() for t in T)
+        np.testing.assert_allclose(c.numpy(), st.c.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(pi.numpy(), st.pi.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(mu.numpy(), st.mu.numpy(), rtol=1e-5, atol=2e-7)
+        np.testing.assert_allclose(var.numpy(), st.var.numpy(), rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(cc.numpy(), st.class_counts.numpy(), rtol=1e-5, atol=1e-7)
+        # and no further from the fp64 state than the fp32 oracle is (factor 2, floor 1e-7)
+        for a, r32, r64 in ((mu, st.mu, st64.mu), (var, st.var, st64.var)):
+            e_ref = (r32.double() - r64).abs().max().item()
+            assert (a.double() - r64).abs().max().item() <= 2 * e_ref + 1e-7
+        assert abs(float(c.double().sum()) - float(st64.c.sum())) < 1e-3
+
+
 def test_predict_is_invariant_to_mode_permutation(ua):
     """SURVEY section 8c property: relabelling the M modes of every class changes nothing but the order of the terms of
     the logsumexp over modes; the per-mode joint log-probabilities are permuted exactly."""
@@ -317,7 +396,7 @@ def test_large_K_paths_are_bit_identical_to_the_one_workgroup_kernels(ua):
             ua.call('ua_class_shard_pack', dotad.data_ptr() + 4 * k0, cd.data_ptr() + 4 * k0 * M, k1 - k0, M, per, gathered[r].data_ptr(), ua.stream_ptr())
         out2 = torch.empty(1, K, device='cuda'); rank2 = torch.empty(1, dtype=torch.int32, device='cuda'); pred2 = torch.empty(1, dtype=torch.int32, device='cuda')
         dz = torch.empty(1, K, device='cuda')
-        ua.call('ua_fuse_logits_sharded', ua.ptr(clip), ua.ptr(gathered), W, per, K, M, 0.02, 0.1, 1, ua.ptr(tgt, torch.int32), ua.ptr(out2),
+        ua.call('ua_fuse_logits_sharded', ua.ptr(clip), ua.ptr(gathered), W, 1, per, K, M, 0.02, 0.1, 1, ua.ptr(tgt, torch.int32), ua.ptr(out2),
                 ua.ptr(rank2, torch.int32), ua.ptr(pred2, torch.int32), ua.ptr(dz), ua.stream_ptr())
         assert torch.equal(out2, out) and torch.equal(rank2, rank) and torch.equal(pred2, pred) and torch.equal(dz.cpu(), dota)
 

@@ -93,8 +93,8 @@ def main():
             del eng
         return
     if a.mode == 'class':
-        # one rank of a W-rank 'class' job: encode its n samples, then per sample of the n*W-sample step its class slice of
-        # the cache step + the fusion from W stand-in buffers (its own, repeated; wire time of the tiny all_gather excluded)
+        # one rank of a W-rank 'class' job: encode its n samples, then for the n*W-sample step its class slice of
+        # the cache step + the chunk's fusion from W stand-in buffers (its own, repeated; wire time of the one all_gather excluded)
         for W in [int(w) for w in a.world.split(',')]:
             eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, a.modes, res_learning=False, chunk=n * W,
                             device=dev, replay_mode='class', emulated_rank=(0, max(W, 2)), overlap=True)
@@ -113,9 +113,8 @@ def main():
                 rs.wait_stream(main_s); feats.record_stream(rs)
                 eng.world = Wm
                 with torch.cuda.stream(rs):
-                    for j in range(n * W):
-                        buf = eng.class_local(feats[j, 0:1], feats[j, 1:2])
-                        eng.class_fuse(buf[None].repeat(Wm, 1), None, final[j:j + 1], None, preds[j:j + 1])
+                    buf = eng.class_local_chunk(feats)
+                    eng.class_fuse_chunk(buf[None].repeat(Wm, 1, 1), None, final, None, preds)
                 eng.world = 1
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.steps

@@ -161,7 +161,7 @@ class TtaEngine:
             # independent, Uni_Adapter.py:336-352): this engine is a single-process engine whatever the job size
             self.world, self.rank = 1, 0
         # 'class' (exact, for large K): features are gathered as in 'replicated', but rank r keeps and
-        # updates only classes [r*per, (r+1)*per) of the GMM state; one small all_gather per SAMPLE re-assembles the scores
+        # updates only classes [r*per, (r+1)*per) of the GMM state; ONE all_gather per chunk re-assembles the scores of its samples
         self.class_mode = self.replay_mode == 'class' and self.world > 1
         if self.class_mode and self.res_learning:
             raise ValueError("replay_mode='class' shards the GMM state by class; residual learning couples all classes "
@@ -177,15 +177,18 @@ class TtaEngine:
             self.class_per = -(-self.K // self.world)
             self.class_k0 = min(self.rank * self.class_per, self.K)
             self.class_k1 = min(self.class_k0 + self.class_per, self.K)
-            self.xbuf = torch.zeros(self.class_per + 2, device=self.dev)
             self.dz_local = torch.zeros(max(1, self.class_per), device=self.dev)
         self._delta = None
         K, D, M, dev = self.K, self.D, self.M, self.dev
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
         self.fh, self.fa = e(1, D), e(1, D)
         self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
-        self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
-        self.inv_var, self.row_const = e(K, M, D), e(K, M)
+        if self.res_learning:               # K x K work arrays of the residual loop (1 GB each at K = 4096, M = 16: only when used)
+            self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
+            self.inv_var, self.row_const = e(K, M, D), e(K, M)
+        else:
+            self.L = self.joint = self.gll = self.ge = self.inv_var = self.row_const = None
+            self.loss = e(1)
         self.tickets = torch.zeros(K, dtype=torch.int32, device=self.dev)      # hand-off counters of ua_align_step
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
         self.count = 0
@@ -204,8 +207,10 @@ class TtaEngine:
         if r is not None:
             s.res, s.adam_m, s.adam_v, s.e, s.norm = (t.data_ptr() for t in (r.res, r.m, r.v, r.e, r.norm))
         s.fhat, s.faug, s.clip_logits, s.prob, s.dota_scores = (t.data_ptr() for t in (self.fh, self.fa, self.z, self.prob, self.dz))
-        s.L, s.joint, s.grad_ll, s.grad_e, s.loss = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge, self.loss))
-        s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
+        s.loss = self.loss.data_ptr()
+        if self.res_learning:
+            s.L, s.joint, s.grad_ll, s.grad_e = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge))
+            s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
         s.tickets = self.tickets.data_ptr()
         return s
 
@@ -324,10 +329,9 @@ class TtaEngine:
                     if t is not None:
                         t.record_stream(rs)
             with torch.cuda.stream(rs):
-                for j in range(n):
-                    buf = self.class_local(feats[j, 0:1], feats[j, 1:2])
-                    self.class_fuse(gather_deltas(buf, self.world, self.group), tgt[j:j + 1] if tgt is not None else None,
-                                    final[j:j + 1], ranks[j:j + 1], preds[j:j + 1])
+                # this rank's class slice stepped through the WHOLE chunk, then one collective, then the fusion of all n samples
+                buf = self.class_local_chunk(feats)
+                self.class_fuse_chunk(gather_deltas(buf, self.world, self.group), tgt, final, ranks, preds)
                 if tgt is not None:
                     self.correct += torch.stack([(ranks < k).sum() for k in (1, 3, 5)])
                     self.count += n
@@ -363,35 +367,51 @@ class TtaEngine:
             self.count += n
         return final, ranks, preds
 
-    # -- 'class' replay mode (exact, large K): per sample, this rank's class slice of the step, then the fusion from the
-    #    W gathered score slices (two halves so that W ranks can be driven in lock-step from one process) -------------
-    def class_local(self, feat, feat_aug):
-        """Clip logits over all K (every rank), predict + fit + fit on classes [k0,k1) of the state, pack the score slice
-        and the partial sum of c.  Returns the (per+2,) exchange buffer."""
+    # -- 'class' replay mode (exact, large K): this rank's class slice of the step for every sample of the chunk, ONE exchange,
+    #    then the fusion of the chunk from the W gathered buffers (two halves so that W ranks can be driven in lock-step from
+    #    one process).  Exact because, with residual learning off, nothing the fusion produces feeds back into the state: fit
+    #    takes the zero-shot prob_map (Uni_Adapter.py:417,430) and mean(c) is only read by the fusion weight (:491). ---------
+    def _class_bufs(self, n):
+        if getattr(self, '_cls_n', 0) < n:
+            self._cls_n = n
+            self.zbuf = torch.empty(n, self.K, device=self.dev)
+            self.xbuf = torch.zeros(n, self.class_per + 2, device=self.dev)
+        return self.zbuf[:n], self.xbuf[:n]
+
+    def class_local_chunk(self, feats):
+        """feats (n,2,D).  Per sample: clip logits over all K (every rank), predict + fit + fit on classes [k0,k1) of the
+        state, pack [score slice | partial sum of c after this sample].  Returns the (n, per+2) exchange buffer."""
         K, M, D = self.K, self.M, self.D
+        n = feats.shape[0]
         k0, kl = self.class_k0, self.class_k1 - self.class_k0
         mdl, st = self.mode_dota_model, lib.stream_ptr()
-        lib.call('ua_clip_logits_pair', lib.ptr(feat), lib.ptr(feat_aug), lib.ptr(self.text), K, D, LOGIT_SCALE, lib.ptr(self.fh),
-                 lib.ptr(self.fa), lib.ptr(self.z), lib.ptr(self.prob), st)                                   # :406,:424,:429
-        if kl:
-            row = 4 * k0 * M
-            lib.call('ua_gmm_step_fused', mdl.mu.data_ptr() + row * D, mdl.var.data_ptr() + row * D, mdl.pi.data_ptr() + row,
-                     mdl.c.data_ptr() + row, mdl.class_counts.data_ptr() + 4 * k0, lib.ptr(self.fh), 1, lib.ptr(self.fh),
-                     lib.ptr(self.fa), self.prob.data_ptr() + 4 * k0, lib.ptr(self.dz_local), kl, M, D, mdl.epsilon, st)   # :416,:417,:430
-        lib.call('ua_class_shard_pack', lib.ptr(self.dz_local), mdl.c.data_ptr() + 4 * k0 * M, kl, M, self.class_per,
-                 lib.ptr(self.xbuf), st)
-        return self.xbuf
+        zbuf, xbuf = self._class_bufs(n)
+        feats = feats.contiguous()
+        row = 4 * k0 * M
+        for j in range(n):
+            f = feats.data_ptr() + 4 * (2 * j) * D
+            lib.call('ua_clip_logits_pair', f, f + 4 * D, lib.ptr(self.text), K, D, LOGIT_SCALE, lib.ptr(self.fh),
+                     lib.ptr(self.fa), zbuf.data_ptr() + 4 * j * K, lib.ptr(self.prob), st)                       # :406,:424,:429
+            if kl:
+                lib.call('ua_gmm_step_fused', mdl.mu.data_ptr() + row * D, mdl.var.data_ptr() + row * D, mdl.pi.data_ptr() + row,
+                         mdl.c.data_ptr() + row, mdl.class_counts.data_ptr() + 4 * k0, lib.ptr(self.fh), 1, lib.ptr(self.fh),
+                         lib.ptr(self.fa), self.prob.data_ptr() + 4 * k0, lib.ptr(self.dz_local), kl, M, D, mdl.epsilon, st)   # :416,:417,:430
+            lib.call('ua_class_shard_pack', lib.ptr(self.dz_local), mdl.c.data_ptr() + 4 * k0 * M, kl, M, self.class_per,
+                     xbuf.data_ptr() + 4 * j * (self.class_per + 2), st)
+        return xbuf
 
-    def class_fuse(self, gathered, target, out_final, out_rank, out_pred):
-        """gathered: (W, per+2) = every rank's class_local buffer in rank order."""
+    def class_fuse_chunk(self, gathered, target, out_final, out_rank, out_pred):
+        """gathered: (W, n, per+2) = every rank's class_local_chunk buffer in rank order; target (n,) int32 or None."""
         gathered = gathered.contiguous()
-        assert gathered.shape == (self.world, self.class_per + 2)
-        lib.call('ua_fuse_logits_sharded', lib.ptr(self.z), lib.ptr(gathered), self.world, self.class_per, self.K, self.M,
+        n = gathered.shape[1]
+        assert gathered.shape == (self.world, n, self.class_per + 2)
+        zbuf, _ = self._class_bufs(n)
+        lib.call('ua_fuse_logits_sharded', lib.ptr(zbuf), lib.ptr(gathered), self.world, n, self.class_per, self.K, self.M,
                  float(self.cfg['rho']), float(self.cfg['eta']), 1, lib.ptr(target, torch.int32) if target is not None else None,
                  lib.ptr(out_final), lib.ptr(out_rank, torch.int32) if target is not None else None, lib.ptr(out_pred, torch.int32),
-                 lib.ptr(self.dz), lib.stream_ptr())                                                          # :491-521
-        self.i += 1
-        self.mode_dota_model.t += 2
+                 None, lib.stream_ptr())                                                                      # :491-521
+        self.i += n
+        self.mode_dota_model.t += 2 * n
 
     # -- 'delta' replay mode: local replay + pack, exchange, merge (three steps so that W ranks can also be driven in
     #    lock-step from one process: tests/test_gpu_harness.py, tools/emulate_scaling.py) ---------------------------

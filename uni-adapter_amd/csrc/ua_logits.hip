@@ -241,28 +241,35 @@ class_shard_pack_kernel(const float* __restrict__ scores, const float* __restric
     if (threadIdx.x == 0) { const float hi = (float)s; out[per] = hi; out[per + 1] = (float)(s - (double)hi); }
 }
 
-// fuse from the W gathered buffers (rank order): dota scores re-assembled, mean(c) from the partial sums.
+// fuse n samples from the W gathered buffers (rank order; buffer of rank r, sample j at gathered[(r*n + j)*(per+2)]):
+// dota scores re-assembled, mean(c) from the partial sums.  One workgroup per sample: nothing the fusion produces feeds back
+// into the state when residual learning is off (fit uses the zero-shot prob_map, Uni_Adapter.py:417,430; mean(c) is only
+// read by the fusion weight :491), so a whole chunk's slices are exchanged with ONE collective and fused afterwards.
 __global__ void __launch_bounds__(1024)
-fuse_logits_sharded_kernel(const float* __restrict__ clip, const float* __restrict__ gathered, int W, int per,
+fuse_logits_sharded_kernel(const float* __restrict__ clip, const float* __restrict__ gathered, int W, int n, int per,
                            int K, int M, float rho, float eta, int batch, const int* __restrict__ target,
                            float* __restrict__ final_logits, int* __restrict__ rank, int* __restrict__ pred,
                            float* __restrict__ dota_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ double sd[16];
     __shared__ float sf[16];
+    const int j = blockIdx.x;
     float* zc = smem; float* zd = smem + K; float* p = smem + 2 * K;
+    const size_t rs = (size_t)n * (per + 2);                           // rank stride
+    const float* gj = gathered + (size_t)j * (per + 2);
     double s = 0.0;
-    for (int r = 0; r < W; ++r) s += (double)gathered[(size_t)r * (per + 2) + per] + (double)gathered[(size_t)r * (per + 2) + per + 1];
+    for (int r = 0; r < W; ++r) s += (double)gj[(size_t)r * rs + per] + (double)gj[(size_t)r * rs + per + 1];
     const float cmean = (float)(s / (double)(K * M));
     const float w = fminf(rho * cmean / (float)batch, eta);
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const int r = i / per;
-        const float d = gathered[(size_t)r * (per + 2) + (i - r * per)];
-        if (dota_out) dota_out[i] = d;
-        zc[i] = clip[i]; zd[i] = w * d;
+        const float d = gj[(size_t)r * rs + (i - r * per)];
+        if (dota_out) dota_out[(size_t)j * K + i] = d;
+        zc[i] = clip[(size_t)j * K + i]; zd[i] = w * d;
     }
     __syncthreads();
-    fuse_core(zc, zd, p, K, sd, sf, target, final_logits, rank, pred);
+    fuse_core(zc, zd, p, K, sd, sf, target ? target + j : nullptr, final_logits + (size_t)j * K, rank ? rank + j : nullptr,
+              pred ? pred + j : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -425,18 +432,18 @@ extern "C" int ua_class_shard_pack(const float* scores, const float* c, int32_t 
     return UA_OK;
 }
 
-extern "C" int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t per, int32_t K, int32_t M,
-                                      float rho, float eta, int32_t batch, const int32_t* target, float* final_logits,
+extern "C" int ua_fuse_logits_sharded(const float* clip_logits, const float* gathered, int32_t W, int32_t n, int32_t per, int32_t K,
+                                      int32_t M, float rho, float eta, int32_t batch, const int32_t* target, float* final_logits,
                                       int32_t* rank, int32_t* pred, float* dota_out, void* stream) {
     UA_CHECK_PTR(clip_logits); UA_CHECK_PTR(gathered); UA_CHECK_PTR(final_logits);
-    if (K <= 0 || M <= 0 || batch <= 0 || W <= 0 || per <= 0 || (int64_t)W * per < K) return UA_EINVAL;
+    if (K <= 0 || M <= 0 || batch <= 0 || W <= 0 || n <= 0 || per <= 0 || (int64_t)W * per < K) return UA_EINVAL;
     const size_t lds = (size_t)(3 * K) * sizeof(float);
     if (lds > 150 * 1024) return UA_EUNSUPPORTED;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(fuse_logits_sharded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return UA_ELAUNCH;
-    hipLaunchKernelGGL(fuse_logits_sharded_kernel, dim3(1), dim3(K > 1024 ? 1024 : 256), lds, ua::as_stream(stream),
-                       clip_logits, gathered, W, per, K, M, rho, eta, batch, target, final_logits, rank, pred, dota_out);
+    hipLaunchKernelGGL(fuse_logits_sharded_kernel, dim3(n), dim3(K > 1024 ? 1024 : 256), lds, ua::as_stream(stream),
+                       clip_logits, gathered, W, n, per, K, M, rho, eta, batch, target, final_logits, rank, pred, dota_out);
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

@@ -72,7 +72,7 @@ SIGNATURES = {
     'ua_gmm_delta_merge': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i32, _p],
     'ua_vec_delta': [_p, _p, _i64, _p, _p],
     'ua_class_shard_pack': [_p, _p, _i32, _i32, _i32, _p, _p],
-    'ua_fuse_logits_sharded': [_p, _p, _i32, _i32, _i32, _i32, _f, _f, _i32, _p, _p, _p, _p, _p, _p],
+    'ua_fuse_logits_sharded': [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, _f, _i32, _p, _p, _p, _p, _p, _p],
     'ua_vec_merge': [_p, _p, _i32, _i64, _i64, _f, _p, _p],
     'ua_to_half': [_p, _p, _i64, _p],
     'ua_dota_predict': [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p],

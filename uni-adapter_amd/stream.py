@@ -20,8 +20,9 @@ Two ways to place the sequential part:
   * 'class' (exact, for large K such as the 1 156-class or 4 096-class banks): features are gathered as in 'replicated', but
     rank r keeps and updates only classes [r*per, (r+1)*per), per = ceil(K/W), of the GMM state - every formula of the cache
     step is independent per class; the couplings are the softmax over K of the zero-shot logits (computed on every rank)
-    and mean(c) in the fusion weight.  One small all_gather per SAMPLE ((per + 2) floats per rank: the score slice and
-    the partial sum of c) re-assembles the scores; the state traffic per sample drops by W.  No residual learning (its
+    and mean(c) in the fusion weight.  ONE all_gather per CHUNK ((n, per + 2) floats per rank: per sample the score slice and
+    the partial sum of c after that sample) re-assembles the scores - exact, because with residual learning off nothing the
+    fusion produces feeds back into the state; the state traffic per sample drops by W.  No residual learning (its
     K x K alignment matrix couples all classes, and is infeasible at such K in the reference as well).
 All three give results identical to the single-process stream.
   * 'delta' (opt-in, NOT exact; the north star's "all-gather of per-rank prototype deltas after each chunk"): every rank
