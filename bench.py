@@ -14,12 +14,14 @@ predict + 2 fits, 10 Adam steps of residual learning, fusion.  Inputs are reside
 the timed region starts.  value = point clouds (samples) per second over all ranks.
 
 The JSON line also carries
-  roofline      - the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches in the
-                  timed region / their summed HIP-event durations, vs the 157.3 TFLOP/s fp32 MFMA peak
-  similarity    - the cache "similarity kernel" (ua_gmm_loglik, BASELINE.json configs[4] shape
-                  K=4096, M=16, D=1024, fp32) and the fused predict+fit+fit pass vs the 8 TB/s HBM peak
-  cpu_baseline  - the CPU oracle (PyTorch-CPU restatement, kind "port") on the host cores, on a
-                  bounded sample of the same workload (rank 0, N=1 only)
+  roofline      - the dominant kernel (the split-f16 MFMA GEMM by default): algorithmic FLOPs of its launches in the timed
+                  region / their summed HIP-event durations (events on the launch stream), vs the dense f16 MFMA peak;
+                  counters of the committed rocprofv3 --pmc passes are attached with their source file named
+  other_gemm_mode - the same stream in the other GEMM mode (exact-f32 MFMA), and where the two modes' predictions agree
+  similarity    - the cache "similarity kernel" (ua_gmm_loglik, BASELINE.json configs[4] shape K=4096, M=16, D=1024, fp32) and
+                  the fused predict+fit+fit pass vs the 8 TB/s HBM peak, checked against the CPU oracle before they are timed
+  cpu_baseline  - the CPU oracle (PyTorch-CPU restatement, kind "port") on the host cores (rank 0, N=1 only): full step,
+                  encoder only, cache only (medians), and the agreement of the HIP stream with it for both GEMM modes
 """
 import argparse
 import json
@@ -52,7 +54,9 @@ def parse():
     ap.add_argument('--depth', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-similarity', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=8)
+    ap.add_argument('--cpu-samples', type=int, default=31, help='full-step leg of the CPU baseline (default: the whole first chunk)')
+    ap.add_argument('--cpu-cache-samples', type=int, default=200, help='cache-only leg of the CPU baseline (median over this many samples)')
+    ap.add_argument('--cpu-cache-warmup', type=int, default=20)
     ap.add_argument('--no-res-learning', action='store_true')
     ap.add_argument('--no-overlap', dest='overlap', action='store_false',
                     help='run the in-order cache replay on the encoder stream instead of a second stream')
@@ -77,21 +81,23 @@ def host_cores():
     return max(1, min(n, cap))
 
 
+PMC_FILES = ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json', 'r02_pmc.json')     # oldest first: later files win
+
+
 def _pmc_table():
-    """Per-kernel counters of the committed PMC passes (newest first): profiles/r01_h_pmc.json, r01_f_pmc.json, r01_pmc_traffic.json."""
+    """Per-kernel counters of the COMMITTED rocprofv3 --pmc passes under profiles/ (collected by tools/pmc_collect.py on an
+    MI355X, corrected as MI355X_MICROARCH.md prescribes).  They are NOT measured by this run: every field that comes from
+    here is tagged with its source file."""
     out = {}
-    for name in ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json'):
+    for name in PMC_FILES:
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
-            out.update(d.get('kernels', d))
+            for k, v in d.get('kernels', d).items():
+                if isinstance(v, dict):
+                    out[k] = dict(v, source='profiles/' + name)
         except Exception:
             pass
     return out
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC passes, or None."""
-    return _pmc_table().get(kernel, {}).get('traffic_bytes')
 
 
 def pmc_probe(kernel):
@@ -99,31 +105,63 @@ def pmc_probe(kernel):
     d = _pmc_table().get(kernel)
     if not d:
         return None
-    return {k: d[k] for k in ('us_per_launch_under_pmc', 'traffic_bytes', 'mfma_busy_frac', 'effective_clock_GHz', 'l2_hit_rate') if k in d}
+    out = {k: d[k] for k in ('us_per_launch_under_pmc', 'traffic_bytes', 'mfma_busy_frac', 'effective_clock_GHz', 'l2_hit_rate') if k in d}
+    out['from_committed_profile'] = d['source']
+    return out
 
 
 def similarity_roofline(dev):
-    """HBM roofline of the similarity kernel at configs[4] size (state 2 x 268 MB > Infinity Cache)."""
+    """HBM roofline of the similarity kernel and of the fused cache step at configs[4] size (state 2 x 268 MB > Infinity
+    Cache).  Before anything is timed, one query and one fused step on this state are checked against the CPU oracle
+    (fp32 and fp64) and the errors are reported."""
     from uni_adapter_amd import lib
+    from oracle import ref_cpu as O                # checker only (not timed, not on the product path)
     K, M, D = 4096, 16, 1024
-    g = torch.Generator(device=dev).manual_seed(0)
-    mu = torch.randn(K, M, D, device=dev, generator=g) * 0.03
-    var = 1e-4 * (1 + torch.rand(K, M, D, device=dev, generator=g))
-    pi = torch.full((K, M), 1.0 / M, device=dev); c = torch.full((K, M), 1.0 / M, device=dev)
-    cc = torch.zeros(K, device=dev)
-    x = torch.nn.functional.normalize(torch.randn(1, D, device=dev, generator=g), dim=1)
-    gam = torch.softmax(torch.randn(1, K, device=dev, generator=g), 1)
+    g = torch.Generator().manual_seed(0)
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    st0 = O.gmm_init(text, M, 1e-4, 1e-4)
+    lab = torch.randint(0, K, (3,), generator=g)
+    xs = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(3, D, generator=g), dim=1)
+    gams = torch.softmax(100.0 * xs @ text.T, 1)
+    mu, var, pi, c, cc = (t.to(dev).contiguous() for t in (st0.mu, st0.var, st0.pi, st0.c, st0.class_counts))
     scores = torch.empty(1, K, device=dev)
     st = lib.stream_ptr()
+    xd, gd = xs.to(dev), gams.to(dev)
 
-    def predict():
-        lib.call('ua_gmm_loglik', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(x), 1, K, M, D, 1e-4, lib.ptr(scores), None, None, st)
+    def predict(i=2):
+        lib.call('ua_gmm_loglik', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), xd.data_ptr() + 4 * i * D, 1, K, M, D, 1e-4, lib.ptr(scores), None, None, st)
 
-    def fused():
-        lib.call('ua_gmm_step_fused', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(c), lib.ptr(cc), lib.ptr(x), 1, lib.ptr(x),
-                 lib.ptr(x), lib.ptr(gam), lib.ptr(scores), K, M, D, 1e-4, st)
+    def fused(i=2):
+        lib.call('ua_gmm_step_fused', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(c), lib.ptr(cc), xd.data_ptr() + 4 * i * D, 1,
+                 xd.data_ptr() + 4 * i * D, xd.data_ptr() + 4 * i * D, gd.data_ptr() + 4 * i * K, lib.ptr(scores), K, M, D, 1e-4, st)
 
-    out = {}
+    # ---- correctness at this size, once, before the timed loops (dota_mixture.py:162-267) ----
+    check = {}
+    ref, ref64 = st0.clone(), O.GmmState(st0.mu.double(), st0.var.double(), st0.pi.double(), st0.c.double(), st0.class_counts.double(), st0.epsilon, st0.t)
+    for i in range(2):                                                      # two stream samples: fused step on the GPU, oracle on the CPU
+        fused(i)
+        got = scores.cpu()
+        xq = xs[i:i + 1].half()
+        r32, r64 = O.gmm_predict(ref, xq), O.gmm_predict(ref64, xq.double())
+        for stt, dt in ((ref, torch.float32), (ref64, torch.float64)):
+            O.gmm_fit(stt, xs[i:i + 1].to(dt), gams[i:i + 1].to(dt)); O.gmm_fit(stt, xs[i:i + 1].to(dt), gams[i:i + 1].to(dt))
+        check[f'fused_step_{i}'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
+                                   'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
+                                   'argmax_identical': bool(int(got.argmax()) == int(r64.argmax()))}
+    check['state_after_2_steps'] = {'max_abs_mu_err_vs_fp64': float((mu.cpu().double() - ref64.mu).abs().max()),
+                                    'max_rel_var_err_vs_fp64': float(((var.cpu().double() - ref64.var).abs() / ref64.var).max()),
+                                    'max_abs_c_err_vs_fp64': float((c.cpu().double() - ref64.c).abs().max())}
+    predict(2)
+    got = scores.cpu()
+    r32, r64 = O.gmm_predict(ref, xs[2:3]), O.gmm_predict(ref64, xs[2:3].double())
+    check['predict'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
+                        'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
+                        'argmax_identical': bool(int(got.argmax()) == int(r64.argmax())), 'score_magnitude': round(float(r64.abs().max()), 1)}
+    del ref, ref64
+    log(f'similarity check at K={K}, M={M}: {check}')
+
+    pmc = _pmc_table()
+    out = {'checked_against_oracle': check}
     for name, fn, nbytes in (('predict', predict, 2.0 * K * M * D * 4), ('fused_step', fused, 4.0 * K * M * D * 4)):
         for _ in range(3):
             fn()
@@ -134,38 +172,106 @@ def similarity_roofline(dev):
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         gbs = nbytes / (ms * 1e-3) / 1e9
+        kern = pmc.get('gmm_loglik_kernel<4>' if name == 'predict' else 'gmm_step1_kernel<4>', {})
         out[name] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                      'frac': round(gbs / PEAK_HBM_GBS, 4),
-                     'traffic': pmc_traffic('gmm_loglik_kernel<4>' if name == 'predict' else 'gmm_step1_kernel<4>'), 'bytes_per_launch': nbytes,
+                     'traffic': kern.get('traffic_bytes'), 'traffic_from_committed_profile': kern.get('source'),
+                     'bytes_per_launch': nbytes,
                      'ms_per_launch': round(ms, 4), 'shape': {'K': K, 'M': M, 'D': D, 'dtype': 'f32'}}
+    # ---- batched-query form on the matrix cores (BASELINE configs[4]: "fp16 feature x prototype MFMA kernel") ----
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.t(), num_modes=M, device=dev)
+    mdl.mu.copy_(mu); mdl.var.copy_(var); mdl.pi.copy_(pi)
+    gq = torch.Generator(device=dev).manual_seed(5)
+    mf = {}
+    evs = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); mdl.mfma_prepare(512); e1.record(); evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms_op = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    mf['operand_build'] = {'ms': round(ms_op, 4), 'GBps': round(16.0 * K * M * D / (ms_op * 1e-3) / 1e9, 1),
+                           'note': 'state -> [1/v | -2 mu/v] split-f16 operand + row constants, once per state version (8 KMD bytes read, 8 KMD written)'}
+    for B in (64, 512):
+        xq = torch.nn.functional.normalize(text[torch.randint(0, K, (B,))].to(dev) + 0.05 * torch.randn(B, D, device=dev, generator=gq), dim=1)
+        ref = torch.cat([O.gmm_predict(O.GmmState(mu.cpu().double(), var.cpu().double(), pi.cpu().double(), c.cpu().double(), cc.cpu().double(), 1e-4, 0),
+                                       xq[i:i + 4].cpu().double()) for i in range(0, 8, 4)])           # fp64 oracle on the first 8 queries
+        for prec, mult in (('split', 3), ('f16', 1)):
+            sc = mdl.predict_mfma(xq, precision=prec, reuse_operand=True)
+            err = float((sc[:8].cpu().double() - ref).abs().max())
+            agree = int((sc[:8].cpu().argmax(1) == ref.argmax(1)).sum())
+            for _ in range(2):
+                mdl.predict_mfma(xq, precision=prec, reuse_operand=True)
+            evs = []
+            for _ in range(8):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); mdl.predict_mfma(xq, precision=prec, reuse_operand=True); e1.record(); evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+            fl = 4.0 * B * K * M * D
+            mf[f'B{B}_{prec}'] = {'bound': 'mfma', 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                                 'executed_frac': round(mult * fl / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                                 'ms_per_launch': round(ms, 4), 'flops_per_launch': fl, 'queries': B,
+                                 'max_abs_score_err_vs_fp64_first8': round(err, 5), 'argmax_identical_first8': f'{agree}/8',
+                                 'state_operand_GBps': round(8.0 * K * M * D / (ms * 1e-3) / 1e9, 1)}
+    out['mfma_batched'] = mf
     return out
 
 
-def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n, cfg):
-    """Oracle (kind 'port') timed on the host cores on the first n samples of the same stream."""
+def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n_full, cfg, cache_feats, n_cache, n_cache_warm):
+    """Oracle (kind 'port') timed on the host cores (SURVEY section 8d protocol): three legs, medians.
+      full_step    - the first n_full samples of the same synthetic stream: 2 encoder forwards + cache step (+ residual learning);
+                     sample 0 is the warm-up (it has no residual-learning step, Uni_Adapter.py:444); median over the rest
+      encoder_only - the 2 encoder forwards of those samples alone (same pass, timed separately)
+      cache_only   - the cache step alone (clip logits, predict, 2 fits, 10 Adam steps, fusion) on a fresh stream fed with
+                     encoder features: n_cache_warm warm-up samples, median over the next n_cache
+    Returns (record, final logits of the full-step samples)."""
     from oracle import ref_cpu as O               # baseline leg only
     torch.set_num_threads(host_cores())
-    log(f'cpu baseline: {torch.get_num_threads()} threads, {n} samples')
+    log(f'cpu baseline: {torch.get_num_threads()} threads; full step on {n_full} samples, cache only on {n_cache_warm}+{n_cache}')
     s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
     enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
-    t_enc = t_cache = 0.0
+    t_enc, t_cache = [], []
     finals = []
     with torch.no_grad():
         enc(torch.cat([xyz[:1], rgb[:1]], -1))     # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    for i in range(n):
+    for i in range(n_full):
         a = time.perf_counter()
         with torch.no_grad():
             f = enc(torch.cat([xyz[i:i + 1], rgb[i:i + 1]], -1))
             fa = enc(torch.cat([xyz[i:i + 1] + 0.05 * noise[i:i + 1], rgb[i:i + 1]], -1))
         b = time.perf_counter()
         finals.append(s.step(f, fa)[2])
-        t_enc += b - a; t_cache += time.perf_counter() - b
-        log(f'cpu sample {i}: enc {b - a:.2f}s cache {time.perf_counter() - b:.2f}s')
-    dt = time.perf_counter() - t0
-    return {'value': round(n / dt, 4), 'unit': 'point-clouds/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'first {n} samples of the same synthetic stream (2 encoder forwards + cache step + residual learning each); '
-                      f'encoder {t_enc / n:.2f} s/sample, cache+residual {t_cache / n:.2f} s/sample'}, torch.cat(finals)
+        c = time.perf_counter()
+        t_enc.append(b - a); t_cache.append(c - b)
+        if i % 4 == 0:
+            log(f'cpu sample {i}: enc {b - a:.2f}s cache {c - b:.2f}s')
+    te, tc = np.array(t_enc[1:]), np.array(t_cache[1:])
+    full = te + tc
+    legs = {'full_step': {'samples': len(full), 'warmup': 1, 'median_s_per_sample': round(float(np.median(full)), 4),
+                          'mean_s_per_sample': round(float(full.mean()), 4), 'value': round(1.0 / float(np.median(full)), 4)},
+            'encoder_only': {'samples': len(te), 'warmup': 1, 'median_s_per_sample': round(float(np.median(te)), 4),
+                             'mean_s_per_sample': round(float(te.mean()), 4), 'value': round(1.0 / float(np.median(te)), 4),
+                             'note': '2 forwards per sample'}}
+    if cache_feats is not None and n_cache > 0:
+        s2 = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
+        ts = []
+        for i in range(n_cache_warm + n_cache):
+            a = time.perf_counter()
+            s2.step(cache_feats[i, 0:1], cache_feats[i, 1:2])
+            ts.append(time.perf_counter() - a)
+            if i % 50 == 0:
+                log(f'cpu cache-only sample {i}: {ts[-1]:.2f}s')
+        ts = np.array(ts[n_cache_warm:])
+        legs['cache_only'] = {'samples': len(ts), 'warmup': n_cache_warm, 'median_s_per_sample': round(float(np.median(ts)), 4),
+                              'mean_s_per_sample': round(float(ts.mean()), 4), 'value': round(1.0 / float(np.median(ts)), 4),
+                              'note': 'fed with the encoder features of the same synthetic stream'}
+    rec = {'value': legs['full_step']['value'], 'unit': 'point-clouds/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': f'samples 1..{n_full - 1} of the same synthetic stream (2 encoder forwards + cache step + residual learning each), '
+                     f'value = 1 / median seconds per sample; legs timed separately',
+           'legs': legs, 'parallel_info': torch.__config__.parallel_info()}
+    return rec, torch.cat(finals)
 
 
 def main():
@@ -206,7 +312,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(precision):
+    def run_mode(precision, want_feats=0):
         """W warm-up + K timed steps of the full loop in one GEMM mode; returns the result fields."""
         model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
                                                 precision=precision)
@@ -273,11 +379,19 @@ def main():
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
                      'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt / world, 4)})
         preds = out[2].clone()
+        feats = None
+        if want_feats:             # encoder features of the head of the stream for the CPU cache-only leg (after the timed region)
+            nf = min(want_feats, xyz.shape[0])
+            with torch.no_grad():
+                fo = torch.cat([model.encode_pc(torch.cat((xyz[j:j + 32], rgb[j:j + 32]), -1)) for j in range(0, nf, 32)])
+                fb = torch.cat([model.encode_pc(torch.cat((xyz[j:j + 32] + 0.05 * noise[j:j + 32], rgb[j:j + 32]), -1)) for j in range(0, nf, 32)])
+            feats = torch.stack([fo, fb], 1).cpu()
         del eng, model
         torch.cuda.empty_cache()
-        return {'value': round(samples / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'roofline': roof, 'first': first}, preds
+        return {'value': round(samples / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'roofline': roof, 'first': first, 'feats': feats}, preds
 
-    main_mode, (res, preds) = a.precision, run_mode(a.precision)
+    do_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    main_mode, (res, preds) = a.precision, run_mode(a.precision, (a.cpu_cache_samples + a.cpu_cache_warmup) if do_cpu else 0)
     out = {
         'metric': 'point-clouds/sec (1024 pts), Uni3D-L + MODE-DOTA M=8 test-time stream (ModelNet40-C shaped)',
         'value': res['value'], 'unit': 'point-clouds/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -299,6 +413,7 @@ def main():
                                    'one GPU: encoder on the main stream, in-order cache replay on a second stream')},
         'roofline': res['roofline'],
     }
+    other, res2 = None, None
     if a.both_modes:
         other = 'f32' if main_mode == 'split' else 'split'
         res2, preds2 = run_mode(other)
@@ -309,24 +424,35 @@ def main():
         pa = {'last_step': f'{int((preds == preds2).sum())}/{preds.numel()}'}
         if res.get('first') is not None and res2.get('first') is not None:
             f1, f2 = res['first'], res2['first']
+            dd = (f1[0] - f2[0]).abs().amax(1)
             pa['first_step'] = f'{int((f1[1] == f2[1]).sum())}/{f1[1].numel()}'
-            pa['first_step_max_abs_logit_diff'] = round(float((f1[0] - f2[0]).abs().max()), 6)
+            pa['first_step_max_abs_logit_diff'] = round(float(dd.max()), 6)
+            pa['first_step_samples_within_1e-3'] = int((dd <= 1e-3).sum())
+            pa['first_step_max_abs_logit_diff_by_sample'] = [round(float(v), 6) for v in dd]
         out['other_gemm_mode']['prediction_agreement_between_modes'] = pa
     if rank == 0 and not a.no_similarity:
         out['similarity'] = similarity_roofline(dev)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if do_cpu:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
-        n = a.cpu_samples
-        out['cpu_baseline'], cpu_final = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg)
-        if res.get('first') is not None and a.warmup > 0 and n <= n_global:
-            # without real data the bench reports agreement with the CPU restatement on the synthetic stream
-            g_final, g_pred = res['first']
-            out['cpu_baseline']['agreement'] = {
-                'samples': n, 'predictions_identical': int((g_pred[:n].long() == cpu_final.argmax(1)).sum()),
-                'max_abs_logit_diff': round(float((g_final[:n] - cpu_final).abs().max()), 6),
-                # per sample: the fp32 chaos of residual learning lets two fp32 arithmetics drift apart
-                # after a handful of samples; the north-star bar of 1e-3 is meaningful on the first ones
-                'max_abs_logit_diff_by_sample': [round(float(v), 6) for v in (g_final[:n] - cpu_final).abs().amax(1)]}
+        n = min(a.cpu_samples, n_global) if a.warmup > 0 else a.cpu_samples
+        out['cpu_baseline'], cpu_final = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg, res.get('feats'),
+                                                      a.cpu_cache_samples, a.cpu_cache_warmup)
+        # without real data the bench reports agreement with the CPU restatement on the synthetic stream - for
+        # BOTH GEMM modes, over the head of the first chunk.  Residual learning makes two fp32 arithmetics drift apart sample by
+        # sample (the reference against itself: tests/golden/g12), so the per-sample list is the informative part.
+        agree = {}
+        for mode, r in ((main_mode, res), (other if a.both_modes else None, res2 if a.both_modes else None)):
+            if mode is None or r.get('first') is None:
+                continue
+            g_final, g_pred = r['first']
+            d = (g_final[:n] - cpu_final).abs().amax(1)
+            top2 = cpu_final.topk(2, dim=1).values
+            agree[mode] = {'samples': n, 'predictions_identical': int((g_pred[:n].long() == cpu_final.argmax(1)).sum()),
+                           'max_abs_logit_diff': round(float(d.max()), 6),
+                           'samples_within_1e-3': int((d <= 1e-3).sum()),
+                           'max_abs_logit_diff_by_sample': [round(float(v), 6) for v in d],
+                           'oracle_top1_minus_top2_min': round(float((top2[:, 0] - top2[:, 1]).min()), 4)}
+        out['cpu_baseline']['agreement'] = agree
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

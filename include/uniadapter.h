@@ -232,6 +232,25 @@ int ua_gemm_split(const void* A, int64_t lda, float a_scale, const void* W, int6
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                   const ua_gemm_epilogue* ep, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MFMA (GEMM-form) similarity kernel: DOTA_mix.predict / _log_likelihood for a BATCH of B queries
+ * (dota_mixture.py:121-156,236-267 with B > 1; Uni_Adapter.py:219-244, the B = K class embeddings of the
+ * alignment matrix).  joint[b,n] = rc[n] - 1/2 ([x_b^2 | x_b] . [1/v_n | -2 mu_n/v_n]), n = k*M+m,
+ * rc[n] = ln(pi_n+1e-10) - 1/2 sum ln v_n - 1/2 sum mu_n^2/v_n, scores[b,k] = logsumexp_m joint[b,k*M+m]:
+ * a (B x 2D).(2D x KM) product on the matrix cores with H32L32 split operands (terms = 3: fp32-class) or
+ * plain fp16 operands (terms = 1: the hi halves only - the BASELINE configs[4] "fp16 feature x prototype"
+ * roofline variant; raw-score error ~0.1, reported, never used for the parity claim).
+ *   ua_gmm_mfma_operand : builds the state-side operand, row constants and per-row scales in `workspace` from
+ *                         (mu, var, pi); valid until the state changes.
+ *   ua_gmm_loglik_mfma  : scores (B,K) and/or joint (B,K*M) for queries x (B,D) against that operand.
+ * workspace: >= ua_gmm_loglik_mfma_workspace_bytes(B,K,M,D) bytes, 256-byte aligned, the same buffer for both calls
+ * (the operand call may pass B = 1).  D % 256 == 0, D <= 2048.                                                       */
+size_t ua_gmm_loglik_mfma_workspace_bytes(int32_t B, int32_t K, int32_t M, int32_t D);
+int ua_gmm_mfma_operand(const float* mu, const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int ua_gmm_loglik_mfma(const float* x, int32_t B, int32_t K, int32_t M, int32_t D, int32_t terms,
+                       float* scores, float* joint, void* workspace, size_t workspace_bytes, void* stream);
+
 /* LayerNorm over the last dim (timm LayerNorm eps 1e-6): rows x cols, cols % 4 == 0, cols<=8192.
  * Columns cols..cols_pad-1 of y are zero-filled (GEMM K padding).                              */
 int ua_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,

@@ -30,62 +30,128 @@ class FeatureFeeder(torch.nn.Module):
         return out.contiguous()
 
 
-@pytest.mark.parametrize('name,chunk,n', [('modelnet40', 16, 32), ('scanobjectnn', 5, 24), ('shapenet55', 1, 16)])
-def test_loop_with_residual_learning_vs_reference_golden(golden_dir, name, chunk, n):
-    """The full --use-mode-dota loop (clip logits, predict, fit x2, 10-step residual learning,
-    fusion) on the HIP path, fed with the golden encoder outputs, against what the reference's own
-    loop body produced on the same stream (golden), and against the fp64 oracle ("truth").
-
-    Residual learning makes the reference CHAOTIC in fp32: the loss routes a gradient through
-    `likelihood_matrix.max()` (Uni_Adapter.py:247) and Adam's first steps are sign-like, so a
-    round-off-level tie flips whole rows of the update.  Measured on the CPU (oracle fp32 vs fp64,
-    DESIGN.md section 5): final logits differ by 0.5 after 5 samples on the ScanObjectNN bank and by
-    >2 later, with identical predictions.  Hence three assertions:
-      1. predictions identical to the reference's at every step;
-      2. until the first chaotic event of either arithmetic, HIP is within 1e-3 of the reference
-         plus the reference's own distance to the truth (the north-star bar, where it is
-         meaningful; on the first samples that is a plain 1e-3);
-      3. until then HIP is at least as close to the fp64 truth as the fp32 reference is (factor 3,
-         floor 1e-3)."""
+def _run_hip_stream(g, n, chunk, res_learning=True, with_targets=True):
     from uni_adapter_amd.Uni_Adapter import TtaEngine
-    g = _load(golden_dir, f'g2_stream_{name}.npz')
     text = torch.from_numpy(g['text'])
-    n = min(n, g['feat'].shape[0])
     feats = torch.stack([torch.from_numpy(g['feat'][:n]), torch.from_numpy(g['feat_aug'][:n])], 1).cuda()
-    model = FeatureFeeder(feats)
-    eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, int(g['M']), res_learning=True, chunk=chunk)
+    eng = TtaEngine(FeatureFeeder(feats), text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, int(g['M']), res_learning=res_learning,
+                    chunk=chunk)
     finals, preds = [], []
-    pc = torch.zeros(n, 8, 3); rgb = torch.ones(n, 8, 3)
     tgt = torch.from_numpy(g['labels'][:n]).int()
-    for s in range(0, n, chunk):
-        f, r, p = eng.process_chunk(pc[s:s + chunk], rgb[s:s + chunk], tgt[s:s + chunk])
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        f, r, p = eng.process_chunk(torch.zeros(m, 8, 3), torch.ones(m, 8, 3), tgt[s0:s0 + m] if with_targets else None)
         finals.append(f.cpu()); preds.append(p.cpu())
-    final = torch.cat(finals).double().numpy(); pred = torch.cat(preds).numpy()
-    gold = g['final'][:n].astype(np.float64)
-    truth_stream = O.TtaStream(text, O.TtaConfig(num_modes=int(g['M'])), dtype=torch.float64)
-    truth = np.stack([truth_stream.step(torch.from_numpy(g['feat'][i:i + 1]).double(), torch.from_numpy(g['feat_aug'][i:i + 1]).double())[2][0].numpy()
-                      for i in range(n)])
-    assert np.array_equal(pred, gold.argmax(1))                                   # 1
-    assert np.array_equal(pred, truth.argmax(1))
-    e_hip_gold = np.abs(final - gold).max(1)
-    e_ref_truth = np.abs(gold - truth).max(1)
-    e_hip_truth = np.abs(final - truth).max(1)
-    print(name, 'HIP vs reference :', np.round(e_hip_gold, 5).tolist())
-    print(name, 'ref vs fp64 truth:', np.round(e_ref_truth, 5).tolist())
-    print(name, 'HIP vs fp64 truth:', np.round(e_hip_truth, 5).tolist())
-    # A chaotic "event" is a discontinuous jump (>= 0.1) of one trajectory away from the others;
-    # each arithmetic has its own (measured: reference at sample 5 on ScanObjectNN, HIP at 17; HIP at
-    # 31 on ModelNet40).  Logit bounds are asserted on the steps before the first event of any pair.
-    first_event = int(np.argmax(np.maximum(e_ref_truth, e_hip_truth) >= 0.1)) if (np.maximum(e_ref_truth, e_hip_truth) >= 0.1).any() else n
-    assert first_event >= 5, first_event
-    pre = slice(0, first_event)
-    noise = np.maximum(np.maximum.accumulate(e_ref_truth), 1e-3)
-    assert (e_hip_gold[:3] <= 1e-3).all()                                         # 2: north-star bar while calm
-    assert (e_hip_gold[pre] <= 1e-3 + 2 * noise[pre]).all(), (e_hip_gold[pre] / noise[pre]).max()
-    assert (e_hip_truth[pre] <= 3 * noise[pre]).all(), (e_hip_truth[pre] / noise[pre]).max()      # 3
+    return torch.cat(finals).double().numpy(), torch.cat(preds).numpy(), eng
+
+
+@pytest.mark.parametrize('name,chunk', [('modelnet40', 16), ('scanobjectnn', 5), ('shapenet55', 1)])
+def test_loop_with_residual_learning_vs_reference_golden(golden_dir, name, chunk):
+    """The full --use-mode-dota loop (clip logits, predict, fit x2, 10-step residual learning, fusion) on the HIP path,
+    fed with the golden encoder outputs, against what the reference's own loop body produced on the same stream - ALL
+    golden steps (48 / 24 / 16):
+      * the prediction of every step equals the reference's;
+      * the first five samples are within the north-star bar of 1e-3 on the final logits.
+    Later samples of a residual-learning stream cannot be held to 1e-3 by ANY fp32 evaluation, the reference's own
+    included: tests/golden/g12 holds the reference run against itself (other thread count, permuted summation orders,
+    fp64) and those runs are 1.3 apart at sample 5 - see test_long_stream_against_the_references_own_spread, which
+    asserts the envelope; here the distance is only reported."""
+    g = _load(golden_dir, f'g2_stream_{name}.npz')
+    n = g['feat'].shape[0]
+    final, pred, eng = _run_hip_stream(g, n, chunk)
+    gold = g['final'].astype(np.float64)
+    e = np.abs(final - gold).max(1)
+    print(name, 'HIP vs reference, max |dlogit| per step:', np.round(e, 5).tolist())
+    assert np.array_equal(pred, g['pred']), np.nonzero(pred != g['pred'])[0]
+    assert np.array_equal(pred, gold.argmax(1))
+    assert (e[:5] <= 1e-3).all(), e[:5]
     acc = eng.accuracy()
-    want1 = 100.0 * float((gold.argmax(1) == g['labels'][:n]).mean())
+    want1 = 100.0 * float((g['pred'] == g['labels']).mean())
     assert abs(acc['acc1'] - want1) < 1e-9
+
+
+def _spread_stats(T, P, x, S):
+    """Leave-one-out statistics of trajectory `x` against the set S of other trajectories (final logits T[v] (n,K), predictions P[v]):
+    diam[i] = largest pairwise distance inside S at step i; nearest / farthest distance of x to S."""
+    dist = lambda u, v: np.abs(T[u] - T[v]).max(1)
+    n = T[x].shape[0]
+    diam = np.zeros(n)
+    for i, u in enumerate(S):
+        for v in S[i + 1:]:
+            diam = np.maximum(diam, dist(u, v))
+    d = np.stack([dist(x, v) for v in S])
+    unanimous = np.all(np.stack([P[v] for v in S]) == P[S[0]][None], 0)
+    return dict(diam=diam, nearest=d.min(0), farthest=d.max(0),
+                over_nearest=int((d.min(0) > np.maximum(diam, 1e-3)).sum()), over_farthest=int((d.max(0) > np.maximum(diam, 1e-3)).sum()),
+                over_2x=int((d.min(0) > np.maximum(2 * diam, 1e-3)).sum()),
+                unanimous=int(unanimous.sum()), differs_where_unanimous=int(((P[x] != P[S[0]]) & unanimous).sum()))
+
+
+def test_long_stream_against_the_references_own_spread(golden_dir):
+    """256-sample residual-learning stream (ModelNet40 bank).  tests/golden/g12 holds the reference's OWN loop body run
+    five ways on it (oracle/make_golden.py: a = as is, b = 8 threads, c = feature dimension permuted, d = class order
+    permuted - all mathematically the same stream in fp32 - and e = fp64).  Those runs agree to < 1e-3 on samples 0-4,
+    are 1.3 apart at sample 5, ~25 apart from sample 64 on, and disagree on 8-22 % of the predictions: the reference is
+    chaotic in fp32 (gradient through likelihood_matrix.max(), Uni_Adapter.py:247-248, and sign-like first Adam steps).
+    The HIP path is therefore held to what the reference holds against itself, every bound calibrated by leave-one-out
+    over the five reference runs (no threshold chosen by this test except the stated slack factors):
+      1. while the reference runs still agree (their diameter <= 1e-3) HIP is within 1e-3 of run a and predicts the same;
+      2. at EVERY step HIP is no farther from the nearest reference run than twice the runs' own diameter (max(1e-3, .));
+      3. the number of steps where HIP is farther from its nearest run than the diameter (1x) is within the leave-one-out
+         range of the reference runs, and so is the literal "farther from SOME run than the diameter" count;
+      4. where all five reference runs predict the same class HIP predicts it too, up to the leave-one-out disagreement
+         rate of the runs themselves (x2 slack); top-1 accuracy lies in the runs' range (+-5 points)."""
+    g = _load(golden_dir, 'g12_long_stream_modelnet40.npz')
+    n = g['feat'].shape[0]
+    final, pred, eng = _run_hip_stream(g, n, 32)
+    V = [str(v) for v in g['variants']]
+    T = {v: g['final_' + v].astype(np.float64) for v in V}
+    P = {v: g['pred_' + v] for v in V}
+    T['hip'], P['hip'] = final, pred
+    loo = {v: _spread_stats(T, P, v, [u for u in V if u != v]) for v in V}
+    h = _spread_stats(T, P, 'hip', V)
+    for v in V:
+        print('reference run', v, {k: loo[v][k] for k in ('over_nearest', 'over_farthest', 'over_2x', 'unanimous', 'differs_where_unanimous')})
+    print('HIP', {k: h[k] for k in ('over_nearest', 'over_farthest', 'over_2x', 'unanimous', 'differs_where_unanimous')})
+    print('HIP vs run a, first 24 steps:', np.round(np.abs(final - T['a']).max(1)[:24], 4).tolist())
+    print('diameter of the runs, first 24 steps:', np.round(h['diam'][:24], 4).tolist())
+    calm = int(np.argmax(h['diam'] > 1e-3)) if (h['diam'] > 1e-3).any() else n                  # 1
+    assert calm >= 3, calm
+    assert (np.abs(final - T['a']).max(1)[:calm] <= 1e-3).all()
+    assert np.array_equal(pred[:calm], P['a'][:calm])
+    assert h['over_2x'] == 0, h['over_2x']                                                        # 2
+    assert max(loo[v]['over_2x'] for v in V) == 0                                                 # (the bound is one the runs meet themselves)
+    assert h['over_nearest'] <= max(loo[v]['over_nearest'] for v in V), (h['over_nearest'], [loo[v]['over_nearest'] for v in V])        # 3
+    assert h['over_farthest'] <= max(loo[v]['over_farthest'] for v in V), (h['over_farthest'], [loo[v]['over_farthest'] for v in V])
+    worst = max(loo[v]['differs_where_unanimous'] / max(1, loo[v]['unanimous']) for v in V)       # 4
+    assert h['differs_where_unanimous'] / h['unanimous'] <= 2 * worst, (h['differs_where_unanimous'], h['unanimous'], worst)
+    accs = [float((P[v] == g['labels']).mean()) for v in V]
+    acc = float((pred == g['labels']).mean())
+    assert min(accs) - 0.05 <= acc <= max(accs) + 0.05, (acc, accs)
+    assert abs(eng.accuracy()['acc1'] - 100.0 * acc) < 1e-9
+
+
+def test_long_stream_without_residual_learning_holds_the_1e_3_bar(golden_dir):
+    """The same 256-sample stream with residual learning off (no chaotic element): final logits within a plain 1e-3 of the
+    CPU oracle in fp64 at every step, predictions identical at every step, and closer to the fp64 result than the fp32
+    oracle is (the kernels sum in fp64)."""
+    g = _load(golden_dir, 'g12_long_stream_modelnet40.npz')
+    n = g['feat'].shape[0]
+    final, pred, _ = _run_hip_stream(g, n, 32, res_learning=False, with_targets=False)
+    text = torch.from_numpy(g['text'])
+    s64 = O.TtaStream(text, O.TtaConfig(num_modes=int(g['M']), res_learning=False), dtype=torch.float64)
+    s32 = O.TtaStream(text, O.TtaConfig(num_modes=int(g['M']), res_learning=False))
+    e64, e32 = np.zeros(n), np.zeros(n)
+    for i in range(n):
+        f, fa = torch.from_numpy(g['feat'][i:i + 1]), torch.from_numpy(g['feat_aug'][i:i + 1])
+        t64 = s64.step(f.double(), fa.double())[2][0].numpy()
+        t32 = s32.step(f, fa)[2][0].double().numpy()
+        e64[i] = np.abs(final[i] - t64).max(); e32[i] = np.abs(t32 - t64).max()
+        assert int(pred[i]) == int(t64.argmax()) == int(t32.argmax()), i
+    print('HIP vs fp64 oracle, max per 32 steps:', [round(float(e64[i:i + 32].max()), 6) for i in range(0, n, 32)])
+    print('fp32 oracle vs fp64 oracle      :', [round(float(e32[i:i + 32].max()), 6) for i in range(0, n, 32)])
+    assert e64.max() <= 1e-3, e64.max()
+    assert e64.max() <= e32.max()
 
 
 def test_end_to_end_vs_oracle_with_encoder():

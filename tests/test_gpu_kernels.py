@@ -235,6 +235,63 @@ def test_fused_cache_step_at_baseline_bank_sizes(ua, K, M, D):
         assert abs(float(c.double().sum()) - float(st64.c.sum())) < 1e-3
 
 
+@pytest.mark.parametrize('K,M,D,B', [(40, 8, 1024, 40), (15, 4, 512, 5), (7, 16, 1280, 33), (9, 3, 768, 64), (55, 1, 256, 300),
+                                     (1156, 8, 1024, 64), (4096, 16, 1024, 96)])
+def test_mfma_similarity_kernel_matches_oracle(ua, K, M, D, B):
+    """ua_gmm_loglik_mfma: the batched similarity as a (B x 2D).(2D x KM) product on the matrix cores (SURVEY N14 / section
+    8d "batched similarity, GEMM form"; dota_mixture.py:121-156,236-267 with B queries) against the fp64 oracle.
+    terms = 3 (split operands, fp32-class), raw scores / joint log-probabilities of magnitude ~3e3-1e4 against fp64:
+      * small problems (B*K*M <= 2^19: the alignment queries) run 16 x 16 blocks with the contraction split over 8 waves and
+        summed in fp64: within the 2e-3 bar of the VALU kernel's tests (measured 7e-4 on scores, 1.6e-3 on joint values of 1e4);
+      * large ones run the 256 x 256 tile GEMM, whose fp32 accumulators take 64 k-steps x 3 products of roundings at
+        ulp(4096..8192) = 0.5e-3..1e-3: within 8e-3 (measured ~5e-3; the VALU kernel stays the parity path for B = 1);
+      arg-max identical in both.  terms = 1 (plain fp16 operands, the BASELINE configs[4] roofline variant): error REPORTED
+    (SURVEY section 7 measured 0.12), asserted only to be finite and < 2.0, arg-max agreement counted."""
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    text, st, g = (_large_bank(K, M, D, 7) if K > 100 else _stream_state(K, M, D, 20, 7))
+    lab = torch.randint(0, K, (B,), generator=g)
+    x = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(B, D, generator=g), dim=1)
+    mdl = DOTA_mix({'epsilon': st.epsilon, 'sigma': 1e-4}, D, K, text.T, num_modes=M)
+    mdl.mu.copy_(st.mu); mdl.var.copy_(st.var); mdl.pi.copy_(st.pi)
+    scores, joint = mdl.predict_mfma(x, precision='split', want_joint=True)
+    scores2 = mdl.predict_mfma(x, precision='split', reuse_operand=True)                    # fused-lse-only path, operand reused
+    valu = mdl.predict(x)
+    s16 = mdl.predict_mfma(x, precision='f16', reuse_operand=True)
+    torch.cuda.synchronize()
+    st64 = _as64(st)
+    e_split = e_joint = e_valu = e_ref = e_f16 = 0.0
+    agree16 = 0
+    for b0 in range(0, B, 8):                                    # the fp64 oracle holds (8,K,M,D) doubles at most
+        xb = x[b0:b0 + 8]
+        r64 = O.gmm_predict(st64, xb.double()); j64 = O.gmm_joint(st64, xb.double())
+        r32 = O.gmm_predict(st, xb)
+        sl = slice(b0, b0 + xb.shape[0])
+        e_split = max(e_split, (scores[sl].cpu().double() - r64).abs().max().item(), (scores2[sl].cpu().double() - r64).abs().max().item())
+        e_joint = max(e_joint, (joint[sl].cpu().double() - j64).abs().max().item())
+        e_valu = max(e_valu, (valu[sl].cpu().double() - r64).abs().max().item())
+        e_ref = max(e_ref, (r32.double() - r64).abs().max().item())
+        e_f16 = max(e_f16, (s16[sl].cpu().double() - r64).abs().max().item())
+        assert torch.equal(scores[sl].cpu().argmax(1), r64.argmax(1))
+        agree16 += int((s16[sl].cpu().argmax(1) == r64.argmax(1)).sum())
+    print(f'K={K} M={M} D={D} B={B}: |score err| vs fp64 - mfma split {e_split:.2e}, joint {e_joint:.2e}, VALU kernel {e_valu:.2e}, '
+          f'fp32 oracle {e_ref:.2e}, mfma f16 {e_f16:.2e} (arg-max agreement {agree16}/{B})')
+    tol = 2e-3 if B * K * M <= (1 << 19) or B <= 32 else 8e-3
+    assert e_split <= tol and e_joint <= tol, (e_split, e_joint, tol)
+    assert np.isfinite(e_f16) and e_f16 < 2.0
+
+
+def test_mfma_similarity_argument_checks(ua):
+    ws = torch.empty(ua.mfma_workspace_bytes(4, 5, 4, 256) + 256, dtype=torch.uint8, device='cuda')
+    x = torch.zeros(4, 256, device='cuda'); sc = torch.zeros(4, 5, device='cuda')
+    with pytest.raises(RuntimeError, match='workspace'):
+        ua.call('ua_gmm_loglik_mfma', ua.ptr(x), 4, 5, 4, 256, 3, ua.ptr(sc), None, ws.data_ptr(), 1024, ua.stream_ptr())
+    with pytest.raises(RuntimeError, match='invalid'):
+        ua.call('ua_gmm_loglik_mfma', ua.ptr(x), 4, 5, 4, 256, 2, ua.ptr(sc), None, ws.data_ptr(), ws.numel(), ua.stream_ptr())
+    with pytest.raises(RuntimeError, match='envelope'):
+        ua.call('ua_gmm_loglik_mfma', ua.ptr(x), 4, 5, 4, 100, 3, ua.ptr(sc), None, ws.data_ptr(), ws.numel(), ua.stream_ptr())
+    assert ua.mfma_workspace_bytes(0, 5, 4, 256) == 0
+
+
 def test_predict_is_invariant_to_mode_permutation(ua):
     """SURVEY section 8c property: relabelling the M modes of every class changes nothing but the order of the terms of
     the logsumexp over modes; the per-mode joint log-probabilities are permuted exactly."""
@@ -267,7 +324,6 @@ def test_fused_step_stream_vs_golden_and_oracle(ua, golden_dir, name):
     mdl = DOTA_mix(cfg, D, K, text.T, num_modes=M)
     s = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False))
     s64 = O.TtaStream(text, O.TtaConfig(num_modes=M, res_learning=False), dtype=torch.float64)
-    noise_dz, noise_fin = 2e-3, 1e-3          # floors: one coherent-logf rounding / the north-star bar
     textd = dev(text)
     fh = torch.empty(1, D, device='cuda'); fa = torch.empty(1, D, device='cuda')
     z = torch.empty(1, K, device='cuda'); prob = torch.empty(1, K, device='cuda'); ent = torch.empty(1, device='cuda')
@@ -280,16 +336,12 @@ def test_fused_step_stream_vs_golden_and_oracle(ua, golden_dir, name):
         ua.call('ua_fuse_logits', ua.ptr(z), ua.ptr(dz), ua.ptr(mdl.c), K, M, 0.02, 0.1, 1, None, ua.ptr(final), None, None, ua.stream_ptr())
         rz, rdz, rfinal, rpred = s.step(f, f2)
         tz, tdz, tfinal, tpred = s64.step(f.double(), f2.double())
-        # The streaming update is ill-conditioned in fp32 (expanded-form variance, softmax over
-        # log-likelihoods of magnitude 3e3): the reference arithmetic itself drifts from the fp64
-        # truth (measured 0.36 on raw scores / 1e-2 on final logits after 350 samples).  The HIP
-        # path must stay as close to the truth as the fp32 reference does (factor 3), never
-        # looser than the floors above, and predictions must be identical.
-        noise_dz = max(noise_dz, (rdz.double() - tdz).abs().max().item())
-        noise_fin = max(noise_fin, (rfinal.double() - tfinal).abs().max().item())
+        # No residual learning -> no chaotic element: a plain 1e-3 on the final logits against the fp64 oracle on every
+        # step of the stream (the north-star bar), raw scores (magnitude 3e3, fp32 ulp 2.4e-4) at the single-step bar of
+        # 2e-3 plus the fp32 oracle's own distance to fp64, predictions identical.
         np.testing.assert_allclose(z.cpu().numpy(), rz.numpy(), rtol=0, atol=2e-4)
-        assert (dz.cpu().double() - tdz).abs().max().item() <= 3 * noise_dz, i
-        assert (final.cpu().double() - tfinal).abs().max().item() <= 3 * noise_fin, i
+        assert (dz.cpu().double() - tdz).abs().max().item() <= 2e-3 + (rdz.double() - tdz).abs().max().item(), i
+        assert (final.cpu().double() - tfinal).abs().max().item() <= 1e-3, (i, (final.cpu().double() - tfinal).abs().max().item())
         assert int(pred.item()) == rpred
         assert int(final.argmax()) == int(rfinal.argmax()) == int(tfinal.argmax())
         if i == 0:      # no residual learning has happened yet in the golden stream either

@@ -210,6 +210,40 @@ def replay():
     print(f'== cache replay: {med / n * 1e3:.1f} us per sample ({n} samples, 10 Adam steps each)')
 
 
+def mfma_sim():
+    """MFMA (GEMM-form) similarity kernel: operand build, query batches, against the VALU kernels on the same state."""
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    from uni_adapter_amd import synthetic
+    print('== MFMA similarity (ua_gmm_loglik_mfma): algorithmic flops 4*B*K*M*D; f16 dense peak 2500 TF')
+    for K, M, D, Bs in ((40, 8, 1024, (40,)), (160, 8, 1024, (160,)), (1156, 8, 1024, (64, 512)), (4096, 16, 1024, (1, 64, 512))):
+        text = synthetic.text_bank(K, D, 1)
+        mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.t(), num_modes=M)
+        g = torch.Generator(device='cuda').manual_seed(1)
+        mdl.var.mul_(1 + torch.rand(K, M, D, device='cuda', generator=g))
+        med, _ = timeit(lambda: mdl.mfma_prepare(max(Bs)))
+        print(f'K={K} M={M}: operand build {med * 1e3:8.1f} us ({16.0 * K * M * D / med / 1e6:7.1f} GB/s of 8 KMD read + 8 KMD written)')
+        for B in Bs:
+            x = torch.nn.functional.normalize(torch.randn(B, D, device='cuda', generator=g), dim=1)
+            mdl.mfma_prepare(B)
+            fl = 4.0 * B * K * M * D
+            for prec, mult in (('split', 3), ('f16', 1)):
+                med, mn = timeit(lambda: mdl.predict_mfma(x, precision=prec, reuse_operand=True))
+                print(f'   B={B:4d} {prec:5s}: {med * 1e3:8.1f} us  {fl / med / 1e9:8.1f} TF/s algorithmic, {mult * fl / med / 1e9:8.1f} executed '
+                      f'({mult * fl / med / 1e9 / 2500:.3f} of f16 peak); state-side operand bytes / time = {8.0 * K * M * D / med / 1e6:7.1f} GB/s')
+            med, mn = timeit(lambda: mdl.predict(x))
+            print(f'   B={B:4d} VALU : {med * 1e3:8.1f} us (ua_gmm_loglik, fp64 sums)')
+        if K <= 160:
+            eng_iv = torch.empty(K, M, D, device='cuda'); rc = torch.empty(K, M, device='cuda'); L = torch.empty(K, K, device='cuda'); J = torch.empty(K, K, M, device='cuda')
+            st = lib.stream_ptr()
+            lib.call('ua_gmm_prepare_alignment', lib.ptr(mdl.var), lib.ptr(mdl.pi), K, M, D, 1e-4, lib.ptr(eng_iv), lib.ptr(rc), st)
+            e = torch.nn.functional.normalize(text.cuda() + 0.01 * torch.randn(K, D, device='cuda', generator=g), dim=1).contiguous()
+            med, mn = timeit(lambda: lib.call('ua_align_forward', lib.ptr(mdl.mu), lib.ptr(eng_iv), lib.ptr(rc), lib.ptr(e), K, K, M, D, lib.ptr(L), lib.ptr(J), st), reps=30)
+            print(f'   B={K:4d} align_fwd_kernel (VALU, hoisted 1/v): {med * 1e3:8.1f} us (best {mn * 1e3:.1f})')
+            mdl.mfma_prepare(K)
+            med, mn = timeit(lambda: mdl.predict_mfma(e, precision='split', want_joint=True, reuse_operand=True), reps=30)
+            print(f'   B={K:4d} mfma small path incl. query operand + joint: {med * 1e3:8.1f} us (best {mn * 1e3:.1f})')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay', 'encoders', 'caches']
     for w in which:

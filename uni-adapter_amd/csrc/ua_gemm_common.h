@@ -38,6 +38,9 @@ struct EpiArgs {
     float* C; long long ldc;
     float* pool; long long ldp; int pool_rows;   // 64 (Uni3D groups) or 32 (PointBERT groups)
     unsigned char* Cs; long long ldcs; float cs_scale;     // optional H32L32 copy of the output
+    // internal extensions (not in the public ua_gemm_epilogue; used by the MFMA similarity kernel, ua_gmm_loglik_mfma):
+    const float* row_scale;        // per-output-row factor applied to the accumulator (operand rows carry their own power-of-two scale)
+    float* lse; long long ld_lse; int lse_group;   // act 4: logsumexp over groups of lse_group (4, 8 or 16) consecutive columns -> lse[m, n / group]
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -88,6 +91,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     // affine may fuse (one rounding instead of two, half the VALU instructions of the row loop)
 #pragma clang fp contract(fast)
     constexpr bool swiglu = ACT == 3;
+    constexpr bool lse = ACT == 4;
     const int lr = lane >> 4, c4 = (lane & 15) * 4;
     const int ncol0 = ncol_base + c4;                                // input column of .x
     const int nout0 = swiglu ? ncol_base / 2 + c4 : ncol0;           // output column of .x
@@ -135,6 +139,14 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
         for (int p = 0; p < 16; ++p)
             if (FULL || m_first + p * 4 < g.M) res[p] = ld4(rp + p * rstep, nout0, n_out, 0.f);
     }
+    float rs[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) rs[p] = 1.f;
+    if (g.row_scale) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (FULL || m_first + p * 4 < g.M) rs[p] = g.row_scale[m_first + p * 4];
+    }
     const bool affine = g.scale || g.shift;
     float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
@@ -153,7 +165,8 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     for (int p = 0; p < 16; ++p) {
         float4 v = vin[p];
         const float4 bp = p < 8 ? ba : bb;
-        v.x = v.x * as + bp.x; v.y = v.y * as + bp.y; v.z = v.z * as + bp.z; v.w = v.w * as + bp.w;
+        const float asr = as * rs[p];
+        v.x = v.x * asr + bp.x; v.y = v.y * asr + bp.y; v.z = v.z * asr + bp.z; v.w = v.w * asr + bp.w;
         if (affine) { v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w; }
         if (ACT == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (ACT == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
@@ -164,6 +177,20 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
             v.x = silu(v.x) * u.x; v.y = silu(v.y) * u.y; v.z = silu(v.z) * u.z; v.w = silu(v.w) * u.w;
         }
         v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
+        if (lse) {
+            // logsumexp over lse_group consecutive columns = 1, 2 or 4 adjacent lanes of this row (torch.logsumexp: max, exp, sum, log)
+            const int G = g.lse_group;                                 // wave-uniform: 4, 8 or 16
+            float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            if (G >= 8) mx = fmaxf(mx, dpp_f<0xB1, 0xF>(mx));          // quad_perm [1,0,3,2]
+            if (G == 16) mx = fmaxf(mx, dpp_f<0x4E, 0xF>(mx));         // quad_perm [2,3,0,1]
+            float sm = (expf(v.x - mx) + expf(v.y - mx)) + (expf(v.z - mx) + expf(v.w - mx));
+            if (G >= 8) sm += dpp_f<0xB1, 0xF>(sm);
+            if (G == 16) sm += dpp_f<0x4E, 0xF>(sm);
+            const float out = mx + logf(sm);
+            const bool writer = (lane & ((G >> 2) - 1)) == 0;
+            if (writer && (FULL || (m_first + p * 4 < g.M && ncol0 < g.N)))
+                g.lse[(size_t)(m_first + p * 4) * g.ld_lse + ncol0 / G] = out;
+        }
         const bool lane_ok = (FULL || m_first + p * 4 < g.M) && active;         // FULL and not SwiGLU: constant true
         if (FULL && !swiglu) {
             if (have_c) *reinterpret_cast<float4*>(cp + p * cstep) = v;
@@ -216,6 +243,7 @@ __device__ __forceinline__ void epilogue_64x64_act(const EpiArgs& g, const float
         case 1:  epilogue_64x64_impl<FULL, 1>(g, stage, lane, mbase, ncol_base); break;
         case 2:  epilogue_64x64_impl<FULL, 2>(g, stage, lane, mbase, ncol_base); break;
         case 3:  epilogue_64x64_impl<FULL, 3>(g, stage, lane, mbase, ncol_base); break;
+        case 4:  epilogue_64x64_impl<FULL, 4>(g, stage, lane, mbase, ncol_base); break;
         default: epilogue_64x64_impl<FULL, 0>(g, stage, lane, mbase, ncol_base); break;
     }
 }

@@ -191,7 +191,9 @@ constexpr int S_BUF = 4 * S_HALF;                    // 65,536 B per K-tile buff
 // MF = 16: v_mfma_f32_16x16x32_f16, accumulators f32x4 acc[8][4] (16x16 blocks; one MFMA covers the whole
 //          32-column K-tile).  Same LDS traffic, registers and matrix-pipe cycles; the chip holds a
 //          higher clock on the 16x16x32 shape under load.
-template <bool FULL, int MF, typename Acc>
+// TERMS = 3: hi*hi + hi*lo + lo*hi (fp32-class).  TERMS = 1: hi*hi only - plain fp16 operands (the lo halves of the
+// lines are staged but never read); MF 16 only (the MFMA similarity kernel's fp16 roofline variant).
+template <bool FULL, int MF, int TERMS, typename Acc>
 __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int n0, int tid, int wm, int wn,
                                                 const bool (&on)[4][2], Acc& acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
@@ -279,7 +281,7 @@ __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int 
         } else {
             // 4 row blocks x 2 column blocks of 16; the three split products of one block are 8 MFMAs apart
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < TERMS; ++term)
 #pragma unroll
                 for (int ib2 = 0; ib2 < 4; ++ib2)
 #pragma unroll
@@ -349,7 +351,7 @@ __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int 
 #undef UA_MFMA16
 }
 
-template <int SCHED>
+template <int SCHED, int TERMS = 3>
 __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by blockIdx.  The tiles of a
     // partial last row panel (here the 32 CLS rows: almost no MFMA work but a full K walk) take the
@@ -422,11 +424,11 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
         for (int j = 0; j < 2; ++j)
             on[i][j] = ((m0 + swm * 128 + i * 32) < g.M) && ((n0 + swn * 64 + j * 32) < g.N);
     if constexpr (SCHED == 16) {
-        if (full) split_mainloop8<true, 16>(g, m0, n0, tid, swm, swn, on, acc);
-        else      split_mainloop8<false, 16>(g, m0, n0, tid, swm, swn, on, acc);
+        if (full) split_mainloop8<true, 16, TERMS>(g, m0, n0, tid, swm, swn, on, acc);
+        else      split_mainloop8<false, 16, TERMS>(g, m0, n0, tid, swm, swn, on, acc);
     } else if constexpr (SCHED == 8) {
-        if (full) split_mainloop8<true, 32>(g, m0, n0, tid, swm, swn, on, acc);
-        else      split_mainloop8<false, 32>(g, m0, n0, tid, swm, swn, on, acc);
+        if (full) split_mainloop8<true, 32, 3>(g, m0, n0, tid, swm, swn, on, acc);
+        else      split_mainloop8<false, 32, 3>(g, m0, n0, tid, swm, swn, on, acc);
     } else {
         const bool late = g.stagger && __builtin_amdgcn_readfirstlane(wid) >= 4;
         if (full) { if (late) split_mainloop<true, true>(g, m0, n0, tid, wm, wn, li, lh, on, acc);
@@ -571,5 +573,351 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     else if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     else            hipLaunchKernelGGL(gemm_split_kernel<2>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+// =============================================================================================
+// MFMA (GEMM-form) similarity kernel: DOTA_mix.predict / _log_likelihood for a BATCH of queries
+// (dota_mixture.py:121-156,236-267 with B queries; Uni_Adapter.py:219-244 with the B = K class
+// embeddings of the alignment matrix).  SURVEY section 2.1 N14 / section 8(d) "batched similarity":
+//
+//   sum_d (x_d - mu_d)^2 / v_d  =  sum_d x_d^2 (1/v_d)  +  sum_d x_d (-2 mu_d / v_d)  +  sum_d mu_d^2 / v_d
+//
+//   joint[b, n] = rc[n] - 1/2 * ( [x_b^2 | x_b] . [1/v_n | -2 mu_n / v_n] ),   n = k*M + m,
+//   rc[n]       = ln(pi_n + 1e-10) - 1/2 sum_d ln v_nd - 1/2 sum_d mu_nd^2 / v_nd,
+//   scores[b,k] = logsumexp_m joint[b, k*M + m]
+//
+// i.e. a (B x 2D) . (2D x KM) product on the matrix cores, with both operands in the H32L32 split
+// format (fp32-class: hi*hi + hi*lo + lo*hi) or - `terms` = 1 - as plain fp16 (hi only), the row
+// constant and the -1/2 as the GEMM epilogue's per-column shift / scale, and the logsumexp over the M
+// modes fused into the epilogue (M = 4, 8, 16; otherwise a second small launch).  Every operand ROW
+// carries its own power-of-two scale (1/v reaches 1e4 and more, x^2 goes down to 1e-6), folded into
+// the epilogue's per-row / per-column factors, so fp16 range is never an issue.
+// The state-side operand is built by gmm_operand_kernel (one pass over mu, var: 8 KMD bytes read,
+// 8 KMD written) and can be reused for any number of query batches while the state is unchanged.
+// =============================================================================================
+namespace {
+
+__device__ __forceinline__ float pow2_scale(float amax) {
+    // largest power of two s with amax * s <= 30000 (fp16 max 65504), clamped to [2^-14, 2^14]
+    if (!(amax > 0.f)) return 1.f;
+    int e;
+    frexpf(30000.0f / amax, &e);                       // 30000/amax = f * 2^e, f in [0.5, 1)
+    e = max(-14, min(14, e - 1));
+    return ldexpf(1.0f, e);
+}
+
+// Contraction layout: K-tile 2i holds features d = 32i..32i+31 of the first part (x^2 | 1/v), K-tile 2i+1 the same
+// features of the second part (x | -2 mu/v), so the running sum of a GEMM accumulator follows
+// sum_{d' < d} ((x - mu)^2 - mu^2)/v instead of first climbing to sum x^2/v (~5e3) and then coming back down: the fp32
+// roundings of the accumulate chain happen at about half the magnitude.
+__device__ __forceinline__ int sim_col(int part, int d) { return (d >> 5) * 64 + part * 32 + (d & 31); }
+
+__device__ __forceinline__ void store_split4(unsigned char* row, int c, float4 v, float s) {
+    ua::f16x4 hi, lo;
+    ua::split4(v, s, hi, lo);
+    unsigned char* q = row + ua::split_col_off(c);
+    *reinterpret_cast<ua::f16x4*>(q) = hi;
+    *reinterpret_cast<ua::f16x4*>(q + 64) = lo;
+}
+
+// one wave per state row n = k*M + m; block = 4 waves
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gmm_operand_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ pi, int KM, float eps,
+                   unsigned char* __restrict__ Wop, float* __restrict__ rc, float* __restrict__ colscale) {
+    constexpr int D = 256 * VEC;
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= KM) return;                                                     // wave-uniform
+    const float4* pm = reinterpret_cast<const float4*>(mu + (size_t)n * D);
+    const float4* pv = reinterpret_cast<const float4*>(var + (size_t)n * D);
+    float4 a[VEC], b[VEC];
+    double ld = 0.0, mq = 0.0;
+    float amax = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float4 m4 = pm[v * 64 + lane], v4 = pv[v * 64 + lane];
+#define UA_OP(F)                                                                           \
+        {                                                                                  \
+            const float rv = fmaxf(v4.F + eps, 1e-8f);                 /* dota_mixture.py:117-119 */ \
+            const float iv = 1.0f / rv;                                                    \
+            ld += (double)logf(rv);                                                        \
+            mq += (double)((m4.F * m4.F) * iv);                                            \
+            a[v].F = iv; b[v].F = (-2.0f * m4.F) * iv;                                     \
+            amax = fmaxf(amax, fmaxf(iv, fabsf(b[v].F)));                                  \
+        }
+        UA_OP(x) UA_OP(y) UA_OP(z) UA_OP(w)
+#undef UA_OP
+    }
+    ld = ua::wave_sum(ld); mq = ua::wave_sum(mq);
+    amax = ua::wave_max(amax);
+    const float s = pow2_scale(amax);
+    unsigned char* row = Wop + (size_t)n * (2 * D) * 4;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        store_split4(row, sim_col(0, c), a[v], s);
+        store_split4(row, sim_col(1, c), b[v], s);
+    }
+    if (lane == 0) {
+        rc[n] = (float)((double)logf(pi[n] + 1e-10f) - 0.5 * ld - 0.5 * mq);
+        colscale[n] = -0.5f / s;
+    }
+}
+
+// one wave per query row b: A row = [x^2 | x] (split), row_scale[b] = 1/s_b
+template <int VEC>
+__global__ void __launch_bounds__(256)
+gmm_query_operand_kernel(const float* __restrict__ x, int B, unsigned char* __restrict__ Aop, float* __restrict__ row_scale) {
+    constexpr int D = 256 * VEC;
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float4* px = reinterpret_cast<const float4*>(x + (size_t)b * D);
+    float4 xv[VEC];
+    float amax = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        xv[v] = px[v * 64 + lane];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(xv[v].x), fabsf(xv[v].y)), fmaxf(fabsf(xv[v].z), fabsf(xv[v].w))));
+    }
+    amax = ua::wave_max(amax);
+    const float s = pow2_scale(fmaxf(amax, amax * amax));
+    unsigned char* row = Aop + (size_t)b * (2 * D) * 4;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        store_split4(row, sim_col(0, c), make_float4(xv[v].x * xv[v].x, xv[v].y * xv[v].y, xv[v].z * xv[v].z, xv[v].w * xv[v].w), s);
+        store_split4(row, sim_col(1, c), xv[v], s);
+    }
+    if (lane == 0) row_scale[b] = 1.0f / s;
+}
+
+// logsumexp over the M modes for mode counts the fused epilogue does not cover: joint (B, K*M) -> scores (B, K)
+__global__ void __launch_bounds__(256)
+lse_modes_kernel(const float* __restrict__ joint, int BK, int M, float* __restrict__ scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BK) return;
+    const float* j = joint + (size_t)i * M;
+    float mx = j[0];
+    for (int m = 1; m < M; ++m) mx = fmaxf(mx, j[m]);
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += expf(j[m] - mx);
+    scores[i] = mx + logf(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-problem form of the MFMA similarity (the B = K alignment queries of residual learning, DOTA_mix.predict on a
+// small batch): the 256x256-tile GEMM above would run such a product on a handful of workgroups with 64 dependent
+// K-steps each.  Here one workgroup owns a 16-query x 16-state-row block of the joint matrix and its 8 waves split
+// the 2D-long contraction (wave w takes K-steps w*nk/8 ..): every wave issues all its operand loads (straight from the
+// H32L32 rows into MFMA fragments - lane = (row l&15, k-group l>>4), one 16-byte chunk per operand half and K-step, no
+// LDS staging), runs nk/8 x TERMS v_mfma_f32_16x16x32_f16, and the 8 partial blocks are summed in fp64 through LDS in a
+// fixed order.  Each partial accumulates only 1/8 of the contraction (magnitude ~6e2 instead of ~5e3) over nk/8 x 3
+// roundings and the cross-wave sum is exact to fp64, so the result is within ~3e-4 of fp64 on raw scores of ~3e3 -
+// the accuracy of the fp64-summing VALU kernel, at the arithmetic cost of 24 MFMAs per wave.
+// grid (ceil(KM/16), ceil(B/16)), block 512.
+// ---------------------------------------------------------------------------------------------
+template <int TERMS, int NKW>      // NKW = K-steps per wave = (2D/32)/8
+__global__ void __launch_bounds__(512)
+gmm_loglik_mfma_small_kernel(const unsigned char* __restrict__ Aop, const unsigned char* __restrict__ Wop,
+                             const float* __restrict__ rc, const float* __restrict__ colscale, const float* __restrict__ row_scale,
+                             int B, int KM, int M, int lse_fused, float* __restrict__ joint, float* __restrict__ scores) {
+    __shared__ double s_part[8][256];
+    __shared__ float s_j[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int lr = lane & 15, kg = lane >> 4;
+    const size_t pitch = (size_t)NKW * 8 * 128;                                     // bytes per operand row (2D columns x 4 B)
+    const unsigned char* pa = Aop + (size_t)min(b0 + lr, B - 1) * pitch + (size_t)w * NKW * 128 + kg * 16;
+    const unsigned char* pw = Wop + (size_t)min(n0 + lr, KM - 1) * pitch + (size_t)w * NKW * 128 + kg * 16;
+    f16x8 ah[NKW], wh[NKW], al[NKW], wl[NKW];
+#pragma unroll
+    for (int t = 0; t < NKW; ++t) {
+        ah[t] = *reinterpret_cast<const f16x8*>(pa + t * 128);
+        wh[t] = *reinterpret_cast<const f16x8*>(pw + t * 128);
+        if (TERMS == 3) {
+            al[t] = *reinterpret_cast<const f16x8*>(pa + t * 128 + 64);
+            wl[t] = *reinterpret_cast<const f16x8*>(pw + t * 128 + 64);
+        }
+    }
+    ua::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKW; ++t) {
+        // W rows as the MFMA's A operand (output rows = state rows), queries as its B operand (output columns = queries):
+        // acc[j] = block[state row 4*kg + j][query lr]
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah[t], acc, 0, 0, 0);
+        if (TERMS == 3) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al[t], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_part[w][lane * 4 + j] = (double)acc[j];
+    __syncthreads();
+    if (tid < 256) {
+        // thread = (query q = tid >> 4, state row c = tid & 15): element of lane (c >> 2) * 16 + q, j = c & 3
+        const int q = tid >> 4, c = tid & 15;
+        const int idx = ((c >> 2) * 16 + q) * 4 + (c & 3);
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += s_part[i][idx];
+        const int b = b0 + q, n = n0 + c;
+        float jv = 0.f;
+        if (b < B && n < KM) {
+            jv = (float)((double)rc[n] + ((double)colscale[n] * (double)row_scale[b]) * v);
+            if (joint) joint[(size_t)b * KM + n] = jv;
+        }
+        s_j[q][c] = jv;
+    }
+    if (!lse_fused || !scores) return;                                              // workgroup-uniform
+    __syncthreads();
+    if (tid < 256) {
+        const int q = tid >> 4, c = tid & 15;
+        const int b = b0 + q, n = n0 + c;
+        if (c % M == 0 && b < B && n < KM) {                                        // M divides 16: the group lies inside the block
+            float mx = s_j[q][c];
+            for (int m = 1; m < M; ++m) mx = fmaxf(mx, s_j[q][c + m]);
+            float sm = 0.f;
+            for (int m = 0; m < M; ++m) sm += expf(s_j[q][c + m] - mx);
+            scores[(size_t)b * (KM / M) + n / M] = mx + logf(sm);                   // torch.logsumexp
+        }
+    }
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct MfmaWs { unsigned char* Wop; float* rc; float* colscale; unsigned char* Aop; float* row_scale; float* joint; size_t total; };
+
+inline MfmaWs mfma_ws_layout(unsigned char* base, int B, int K, int M, int D, bool need_joint) {
+    MfmaWs w{};
+    size_t o = 0;
+    const size_t KM = (size_t)K * M;
+    w.Wop = base + o; o += align256(KM * 2 * D * 4);
+    w.rc = reinterpret_cast<float*>(base + o); o += align256(KM * 4);
+    w.colscale = reinterpret_cast<float*>(base + o); o += align256(KM * 4);
+    w.Aop = base + o; o += align256((size_t)B * 2 * D * 4);
+    w.row_scale = reinterpret_cast<float*>(base + o); o += align256((size_t)B * 4);
+    if (need_joint) { w.joint = reinterpret_cast<float*>(base + o); o += align256((size_t)B * KM * 4); }
+    w.total = o;
+    return w;
+}
+
+inline bool lse_fusable(int M) { return M == 4 || M == 8 || M == 16; }     // both paths fuse these (the small path also M = 1, 2)
+
+template <typename F>
+int dispatch_vec_op(int D, F&& f) {
+    switch (D / 256) {
+        case 1: return f(std::integral_constant<int, 1>{});
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 3: return f(std::integral_constant<int, 3>{});
+        case 4: return f(std::integral_constant<int, 4>{});
+        case 5: return f(std::integral_constant<int, 5>{});
+        case 6: return f(std::integral_constant<int, 6>{});
+        case 7: return f(std::integral_constant<int, 7>{});
+        case 8: return f(std::integral_constant<int, 8>{});
+        default: return UA_EUNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ua_gmm_loglik_mfma_workspace_bytes(int32_t B, int32_t K, int32_t M, int32_t D) {
+    if (B <= 0 || K <= 0 || M <= 0 || D <= 0) return 0;
+    return mfma_ws_layout(nullptr, B, K, M, D, !lse_fusable(M)).total;
+}
+
+extern "C" int ua_gmm_mfma_operand(const float* mu, const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(var); UA_CHECK_PTR(pi); UA_CHECK_PTR(workspace);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(var);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return UA_EALIGN;
+    if (K <= 0 || M <= 0 || D <= 0) return UA_EINVAL;
+    if (D % 256 != 0 || D > 2048) return UA_EUNSUPPORTED;
+    const MfmaWs w = mfma_ws_layout(reinterpret_cast<unsigned char*>(workspace), 1, K, M, D, false);
+    if (workspace_bytes < w.total) return UA_EWORKSPACE;
+    const int KM = K * M;
+    return dispatch_vec_op(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        hipLaunchKernelGGL(gmm_operand_kernel<VEC>, dim3((KM + 3) / 4), dim3(256), 0, ua::as_stream(stream), mu, var, pi, KM, eps,
+                           w.Wop, w.rc, w.colscale);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+}
+
+extern "C" int ua_gmm_loglik_mfma(const float* x, int32_t B, int32_t K, int32_t M, int32_t D, int32_t terms,
+                                  float* scores, float* joint, void* workspace, size_t workspace_bytes, void* stream) {
+    UA_CHECK_PTR(x); UA_CHECK_PTR(workspace); UA_CHECK_ALIGN16(x);
+    if (!scores && !joint) return UA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return UA_EALIGN;
+    if (B <= 0 || K <= 0 || M <= 0 || D <= 0 || (terms != 1 && terms != 3)) return UA_EINVAL;
+    if (D % 256 != 0 || D > 2048) return UA_EUNSUPPORTED;
+    const bool fused = lse_fusable(M);
+    const MfmaWs w = mfma_ws_layout(reinterpret_cast<unsigned char*>(workspace), B, K, M, D, !fused);
+    if (workspace_bytes < w.total) return UA_EWORKSPACE;
+    if (joint && (reinterpret_cast<uintptr_t>(joint) & 15u) != 0) return UA_EALIGN;
+    hipStream_t st = ua::as_stream(stream);
+    const int KM = K * M, K2 = 2 * D;
+    int rc = dispatch_vec_op(D, [&](auto vec) {
+        constexpr int VEC = decltype(vec)::value;
+        hipLaunchKernelGGL(gmm_query_operand_kernel<VEC>, dim3((B + 3) / 4), dim3(256), 0, st, x, B, w.Aop, w.row_scale);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
+    });
+    if (rc) return rc;
+    // small problems: 16 x 16 blocks with the contraction split over the 8 waves of a workgroup (accurate and parallel);
+    // large ones (the BASELINE configs[4] roofline shapes): the 256 x 256 tile GEMM
+    static const int force_path = [] { const char* e = getenv("UA_MFMA_SIM_PATH"); return e ? atoi(e) : 0; }();   // 1 small, 2 tiles (A/B aid)
+    const bool small = (KM % 4 != 0) || (force_path ? force_path == 1 : ((long long)B * KM <= (1ll << 19) || B <= 32));   // (the tile path stores float4 rows)
+    if (small) {
+        const bool sfused = scores && (16 % M == 0);
+        float* jsmall = joint ? joint : (sfused ? nullptr : w.joint ? w.joint : nullptr);
+        if (!sfused && scores && !jsmall) return UA_EWORKSPACE;
+        const dim3 grid((KM + 15) / 16, (B + 15) / 16);
+        const int nkw = K2 / 32 / 8;
+#define UA_SMALL(T, N) hipLaunchKernelGGL((gmm_loglik_mfma_small_kernel<T, N>), grid, dim3(512), 0, st, w.Aop, w.Wop, w.rc, w.colscale, \
+                                          w.row_scale, B, KM, M, sfused ? 1 : 0, jsmall, scores)
+        if (terms == 3) {
+            switch (nkw) { case 2: UA_SMALL(3, 2); break; case 4: UA_SMALL(3, 4); break; case 6: UA_SMALL(3, 6); break; case 8: UA_SMALL(3, 8); break;
+                           case 10: UA_SMALL(3, 10); break; case 12: UA_SMALL(3, 12); break; case 14: UA_SMALL(3, 14); break; case 16: UA_SMALL(3, 16); break;
+                           default: return UA_EUNSUPPORTED; }
+        } else {
+            switch (nkw) { case 2: UA_SMALL(1, 2); break; case 4: UA_SMALL(1, 4); break; case 6: UA_SMALL(1, 6); break; case 8: UA_SMALL(1, 8); break;
+                           case 10: UA_SMALL(1, 10); break; case 12: UA_SMALL(1, 12); break; case 14: UA_SMALL(1, 14); break; case 16: UA_SMALL(1, 16); break;
+                           default: return UA_EUNSUPPORTED; }
+        }
+#undef UA_SMALL
+        UA_LAUNCH_CHECK();
+        if (!sfused && scores) {
+            hipLaunchKernelGGL(lse_modes_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, jsmall, B * K, M, scores);
+            UA_LAUNCH_CHECK();
+        }
+        return UA_OK;
+    }
+    SplitArgs g{};
+    g.A = w.Aop; g.W = w.Wop; g.lda = K2; g.ldw = K2; g.M = B; g.N = KM; g.K = K2;
+    g.ep = EpiArgs{};
+    g.ep.M = B; g.ep.N = KM; g.ep.acc_scale = 1.0f;
+    g.ep.scale = w.colscale; g.ep.shift = w.rc; g.ep.row_scale = w.row_scale;
+    float* jout = joint ? joint : (fused ? nullptr : w.joint);
+    g.ep.C = jout; g.ep.ldc = KM;
+    if (fused && scores) { g.ep.act = 4; g.ep.lse = scores; g.ep.ld_lse = K; g.ep.lse_group = M; }
+    const int tiles_m = (B + SBM - 1) / SBM, tiles_n = (KM + SBN - 1) / SBN;
+    g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
+    g.block_order = 1; g.stagger = 1;
+    const size_t lds = (size_t)S_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+        attr_set = true;
+    }
+    if (terms == 3) hipLaunchKernelGGL((gemm_split_kernel<16, 3>), dim3(g.n_tiles), dim3(512), lds, st, g);
+    else            hipLaunchKernelGGL((gemm_split_kernel<16, 1>), dim3(g.n_tiles), dim3(512), lds, st, g);
+    UA_LAUNCH_CHECK();
+    if (!fused && scores) {
+        hipLaunchKernelGGL(lse_modes_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, jout, B * K, M, scores);
+        UA_LAUNCH_CHECK();
+    }
     return UA_OK;
 }

@@ -115,6 +115,42 @@ class DOTA_mix(nn.Module):
             return scores + torch.log(p_k + 1e-10).unsqueeze(0)
         return scores
 
+    # ---- MFMA (GEMM-form) similarity for query batches (include/uniadapter.h: ua_gmm_loglik_mfma) ----
+    def _mfma_ws(self, B):
+        K, M, D = self._dims()
+        need = lib.mfma_workspace_bytes(B, K, M, D)
+        ws = getattr(self, '_mfma_buf', None)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._mfma_buf, self._mfma_valid = ws, False
+        return ws
+
+    def mfma_prepare(self, B=1):
+        """Build the state-side MFMA operand (1/v | -2 mu/v as split fp16 pairs, row constants) from the CURRENT state.
+        Valid until the next fit(); predict_mfma(..., reuse_operand=True) then skips this pass."""
+        K, M, D = self._dims()
+        ws = self._mfma_ws(B)
+        lib.call('ua_gmm_mfma_operand', lib.ptr(self.mu), lib.ptr(self.var), lib.ptr(self.pi), K, M, D, self.epsilon,
+                 ws.data_ptr(), ws.numel(), lib.stream_ptr())
+        self._mfma_valid = True
+
+    def predict_mfma(self, x, precision='split', want_joint=False, reuse_operand=False):
+        """predict() for a batch of queries as a (B x 2D).(2D x KM) product on the matrix cores.  precision 'split':
+        fp32-class (three f16 products per term); 'f16': plain fp16 operands (roofline variant, raw-score error ~0.1).
+        Returns scores (B,K) [and joint (B,K,M)]."""
+        x = x.to(self.device).float().contiguous()
+        K, M, D = self._dims()
+        B = x.shape[0]
+        ws = self._mfma_ws(B)
+        if not (reuse_operand and getattr(self, '_mfma_valid', False)):
+            self.mfma_prepare(B)
+            ws = self._mfma_buf
+        scores = torch.empty(B, K, device=self.device, dtype=torch.float32)
+        joint = torch.empty(B, K, M, device=self.device, dtype=torch.float32) if want_joint else None
+        lib.call('ua_gmm_loglik_mfma', lib.ptr(x), B, K, M, D, {'split': 3, 'f16': 1}[precision], lib.ptr(scores),
+                 lib.ptr(joint) if want_joint else None, ws.data_ptr(), ws.numel(), lib.stream_ptr())
+        return (scores, joint) if want_joint else scores
+
     def joint(self, x):
         """Extension: (scores (B,K), joint (B,K,M)) in one launch (batched alignment forward)."""
         x = x.contiguous()
@@ -136,6 +172,7 @@ class DOTA_mix(nn.Module):
                  lib.ptr(self.class_counts), lib.ptr(x), lib.ptr(g), B, K, M, D, self.epsilon,
                  lib.stream_ptr())
         self.t += B
+        self._mfma_valid = False
 
     def update(self):
         """No-op kept for API compatibility (dota_mixture.py:269-274)."""
@@ -151,4 +188,5 @@ class DOTA_mix(nn.Module):
                  lib.ptr(self.class_counts), lib.ptr(xq), 1 if round_query_fp16 else 0, lib.ptr(x1), lib.ptr(x2),
                  lib.ptr(gamma_class), lib.ptr(scores), K, M, D, self.epsilon, lib.stream_ptr())
         self.t += 2
+        self._mfma_valid = False
         return scores

@@ -90,12 +90,16 @@ SIGNATURES = {
     'ua_add_pos': [_p, _p, _p, _i32, _i32, _i32, _p],
     'ua_cls_max_concat': [_p, _p, _i32, _i32, _i32, _p],
     'ua_tta_chunk': [C.POINTER(TtaState), _p, _p, _i32, _i64, _i64, _p, _p, _p, _p],
+    'ua_gmm_mfma_operand': [_p, _p, _p, _i32, _i32, _i32, _f, _p, C.c_size_t, _p],
+    'ua_gmm_loglik_mfma': [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, C.c_size_t, _p],
 }
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)       # AttributeError here = header and library out of sync
     _fn.argtypes = _args
     _fn.restype = C.c_int
+_lib.ua_gmm_loglik_mfma_workspace_bytes.restype = C.c_size_t
+_lib.ua_gmm_loglik_mfma_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
 _lib.ua_version.restype = C.c_int
 _lib.ua_strerror.restype = C.c_char_p
 _lib.ua_strerror.argtypes = [C.c_int]
@@ -103,6 +107,10 @@ _lib.ua_strerror.argtypes = [C.c_int]
 
 def version():
     return _lib.ua_version()
+
+
+def mfma_workspace_bytes(B, K, M, D):
+    return int(_lib.ua_gmm_loglik_mfma_workspace_bytes(B, K, M, D))
 
 
 def strerror(code):
