@@ -112,18 +112,19 @@ def pmc_probe(kernel):
 
 def similarity_roofline(dev):
     """HBM roofline of the similarity kernel and of the fused cache step at configs[4] size (state 2 x 268 MB > Infinity
-    Cache).  Before anything is timed, one query and one fused step on this state are checked against the CPU oracle
-    (fp32 and fp64) and the errors are reported."""
+    Cache), and the batched-query MFMA form.  BEFORE anything is timed, two fused steps, one query and one 8-query MFMA batch
+    are run on a freshly initialised state and their outputs kept; the cpu_baseline leg compares them with the CPU oracle
+    (fp32 and fp64) and attaches the errors as `checked_against_oracle` (the oracle is imported only there)."""
     from uni_adapter_amd import lib
-    from oracle import ref_cpu as O                # checker only (not timed, not on the product path)
+    from uni_adapter_amd.dota_mixture import DOTA_mix
     K, M, D = 4096, 16, 1024
     g = torch.Generator().manual_seed(0)
     text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
-    st0 = O.gmm_init(text, M, 1e-4, 1e-4)
     lab = torch.randint(0, K, (3,), generator=g)
     xs = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(3, D, generator=g), dim=1)
     gams = torch.softmax(100.0 * xs @ text.T, 1)
-    mu, var, pi, c, cc = (t.to(dev).contiguous() for t in (st0.mu, st0.var, st0.pi, st0.c, st0.class_counts))
+    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.t(), num_modes=M, device=dev)
+    mu, var, pi, c, cc = mdl.mu, mdl.var, mdl.pi, mdl.c, mdl.class_counts
     scores = torch.empty(1, K, device=dev)
     st = lib.stream_ptr()
     xd, gd = xs.to(dev), gams.to(dev)
@@ -135,33 +136,22 @@ def similarity_roofline(dev):
         lib.call('ua_gmm_step_fused', lib.ptr(mu), lib.ptr(var), lib.ptr(pi), lib.ptr(c), lib.ptr(cc), xd.data_ptr() + 4 * i * D, 1,
                  xd.data_ptr() + 4 * i * D, xd.data_ptr() + 4 * i * D, gd.data_ptr() + 4 * i * K, lib.ptr(scores), K, M, D, 1e-4, st)
 
-    # ---- correctness at this size, once, before the timed loops (dota_mixture.py:162-267) ----
-    check = {}
-    ref, ref64 = st0.clone(), O.GmmState(st0.mu.double(), st0.var.double(), st0.pi.double(), st0.c.double(), st0.class_counts.double(), st0.epsilon, st0.t)
-    for i in range(2):                                                      # two stream samples: fused step on the GPU, oracle on the CPU
+    # ---- outputs for the correctness check at this size, produced once, before the timed loops (dota_mixture.py:162-267) ----
+    chk = {'K': K, 'M': M, 'D': D, 'text': text, 'xs': xs, 'gams': gams, 'fused_scores': []}
+    for i in range(2):                                                      # two stream samples (the sample fitted twice)
         fused(i)
-        got = scores.cpu()
-        xq = xs[i:i + 1].half()
-        r32, r64 = O.gmm_predict(ref, xq), O.gmm_predict(ref64, xq.double())
-        for stt, dt in ((ref, torch.float32), (ref64, torch.float64)):
-            O.gmm_fit(stt, xs[i:i + 1].to(dt), gams[i:i + 1].to(dt)); O.gmm_fit(stt, xs[i:i + 1].to(dt), gams[i:i + 1].to(dt))
-        check[f'fused_step_{i}'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
-                                   'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
-                                   'argmax_identical': bool(int(got.argmax()) == int(r64.argmax()))}
-    check['state_after_2_steps'] = {'max_abs_mu_err_vs_fp64': float((mu.cpu().double() - ref64.mu).abs().max()),
-                                    'max_rel_var_err_vs_fp64': float(((var.cpu().double() - ref64.var).abs() / ref64.var).max()),
-                                    'max_abs_c_err_vs_fp64': float((c.cpu().double() - ref64.c).abs().max())}
+        chk['fused_scores'].append(scores.cpu().clone())
+    chk['state'] = tuple(t.cpu().clone() for t in (mu, var, pi, c))
     predict(2)
-    got = scores.cpu()
-    r32, r64 = O.gmm_predict(ref, xs[2:3]), O.gmm_predict(ref64, xs[2:3].double())
-    check['predict'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
-                        'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
-                        'argmax_identical': bool(int(got.argmax()) == int(r64.argmax())), 'score_magnitude': round(float(r64.abs().max()), 1)}
-    del ref, ref64
-    log(f'similarity check at K={K}, M={M}: {check}')
+    chk['predict_scores'] = scores.cpu().clone()
+    gq = torch.Generator().manual_seed(5)
+    xq8 = torch.nn.functional.normalize(text[torch.randint(0, K, (8,), generator=gq)] + 0.05 * torch.randn(8, D, generator=gq), dim=1)
+    chk['xq8'] = xq8
+    chk['mfma_split8'] = mdl.predict_mfma(xq8.to(dev), precision='split').cpu()
+    chk['mfma_f16_8'] = mdl.predict_mfma(xq8.to(dev), precision='f16', reuse_operand=True).cpu()
 
     pmc = _pmc_table()
-    out = {'checked_against_oracle': check}
+    out = {}
     for name, fn, nbytes in (('predict', predict, 2.0 * K * M * D * 4), ('fused_step', fused, 4.0 * K * M * D * 4)):
         for _ in range(3):
             fn()
@@ -179,10 +169,6 @@ def similarity_roofline(dev):
                      'bytes_per_launch': nbytes,
                      'ms_per_launch': round(ms, 4), 'shape': {'K': K, 'M': M, 'D': D, 'dtype': 'f32'}}
     # ---- batched-query form on the matrix cores (BASELINE configs[4]: "fp16 feature x prototype MFMA kernel") ----
-    from uni_adapter_amd.dota_mixture import DOTA_mix
-    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.t(), num_modes=M, device=dev)
-    mdl.mu.copy_(mu); mdl.var.copy_(var); mdl.pi.copy_(pi)
-    gq = torch.Generator(device=dev).manual_seed(5)
     mf = {}
     evs = []
     for _ in range(5):
@@ -192,14 +178,10 @@ def similarity_roofline(dev):
     ms_op = float(np.median([a.elapsed_time(b) for a, b in evs]))
     mf['operand_build'] = {'ms': round(ms_op, 4), 'GBps': round(16.0 * K * M * D / (ms_op * 1e-3) / 1e9, 1),
                            'note': 'state -> [1/v | -2 mu/v] split-f16 operand + row constants, once per state version (8 KMD bytes read, 8 KMD written)'}
+    gq = torch.Generator(device=dev).manual_seed(5)
     for B in (64, 512):
         xq = torch.nn.functional.normalize(text[torch.randint(0, K, (B,))].to(dev) + 0.05 * torch.randn(B, D, device=dev, generator=gq), dim=1)
-        ref = torch.cat([O.gmm_predict(O.GmmState(mu.cpu().double(), var.cpu().double(), pi.cpu().double(), c.cpu().double(), cc.cpu().double(), 1e-4, 0),
-                                       xq[i:i + 4].cpu().double()) for i in range(0, 8, 4)])           # fp64 oracle on the first 8 queries
         for prec, mult in (('split', 3), ('f16', 1)):
-            sc = mdl.predict_mfma(xq, precision=prec, reuse_operand=True)
-            err = float((sc[:8].cpu().double() - ref).abs().max())
-            agree = int((sc[:8].cpu().argmax(1) == ref.argmax(1)).sum())
             for _ in range(2):
                 mdl.predict_mfma(xq, precision=prec, reuse_operand=True)
             evs = []
@@ -213,22 +195,54 @@ def similarity_roofline(dev):
                                  'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                  'executed_frac': round(mult * fl / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                  'ms_per_launch': round(ms, 4), 'flops_per_launch': fl, 'queries': B,
-                                 'max_abs_score_err_vs_fp64_first8': round(err, 5), 'argmax_identical_first8': f'{agree}/8',
                                  'state_operand_GBps': round(8.0 * K * M * D / (ms * 1e-3) / 1e9, 1)}
     out['mfma_batched'] = mf
-    return out
+    return out, chk
 
 
-def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n_full, cfg, cache_feats, n_cache, n_cache_warm):
+def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n_full, cfg, cache_feats, n_cache, n_cache_warm, sim_check=None):
     """Oracle (kind 'port') timed on the host cores (SURVEY section 8d protocol): three legs, medians.
       full_step    - the first n_full samples of the same synthetic stream: 2 encoder forwards + cache step (+ residual learning);
                      sample 0 is the warm-up (it has no residual-learning step, Uni_Adapter.py:444); median over the rest
       encoder_only - the 2 encoder forwards of those samples alone (same pass, timed separately)
       cache_only   - the cache step alone (clip logits, predict, 2 fits, 10 Adam steps, fusion) on a fresh stream fed with
                      encoder features: n_cache_warm warm-up samples, median over the next n_cache
+    With `sim_check` (outputs similarity_roofline() produced before its timed loops at K=4096, M=16) the same leg also checks
+    those against the oracle in fp32 / fp64 -> record['similarity_check'].
     Returns (record, final logits of the full-step samples)."""
     from oracle import ref_cpu as O               # baseline leg only
     torch.set_num_threads(host_cores())
+    sim = None
+    if sim_check is not None:
+        q = sim_check
+        ref = O.gmm_init(q['text'], q['M'], 1e-4, 1e-4)
+        as64 = lambda s_: O.GmmState(s_.mu.double(), s_.var.double(), s_.pi.double(), s_.c.double(), s_.class_counts.double(), s_.epsilon, s_.t)
+        ref64 = as64(ref)
+        sim = {}
+        for i in range(2):
+            xq = q['xs'][i:i + 1].half()
+            r32, r64 = O.gmm_predict(ref, xq), O.gmm_predict(ref64, xq.double())
+            for stt, dt in ((ref, torch.float32), (ref64, torch.float64)):
+                O.gmm_fit(stt, q['xs'][i:i + 1].to(dt), q['gams'][i:i + 1].to(dt)); O.gmm_fit(stt, q['xs'][i:i + 1].to(dt), q['gams'][i:i + 1].to(dt))
+            got = q['fused_scores'][i]
+            sim[f'fused_step_{i}'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
+                                     'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
+                                     'argmax_identical': bool(int(got.argmax()) == int(r64.argmax()))}
+        gmu, gvar, gpi, gc = q['state']
+        sim['state_after_2_steps'] = {'max_abs_mu_err_vs_fp64': float((gmu.double() - ref64.mu).abs().max()),
+                                      'max_rel_var_err_vs_fp64': float(((gvar.double() - ref64.var).abs() / ref64.var).max()),
+                                      'max_abs_c_err_vs_fp64': float((gc.double() - ref64.c).abs().max())}
+        r32, r64 = O.gmm_predict(ref, q['xs'][2:3]), O.gmm_predict(ref64, q['xs'][2:3].double())
+        got = q['predict_scores']
+        sim['predict'] = {'max_abs_score_err_vs_fp64': round(float((got.double() - r64).abs().max()), 6),
+                          'oracle_fp32_vs_fp64': round(float((r32.double() - r64).abs().max()), 6),
+                          'argmax_identical': bool(int(got.argmax()) == int(r64.argmax())), 'score_magnitude': round(float(r64.abs().max()), 1)}
+        r64 = torch.cat([O.gmm_predict(ref64, q['xq8'][i:i + 4].double()) for i in (0, 4)])
+        for key, name in (('mfma_split8', 'mfma_batched_split'), ('mfma_f16_8', 'mfma_batched_f16')):
+            sim[name] = {'queries': 8, 'max_abs_score_err_vs_fp64': round(float((q[key].double() - r64).abs().max()), 5),
+                         'argmax_identical': f"{int((q[key].argmax(1) == r64.argmax(1)).sum())}/8"}
+        del ref, ref64
+        log(f'similarity check at K={q["K"]}, M={q["M"]}: {sim}')
     log(f'cpu baseline: {torch.get_num_threads()} threads; full step on {n_full} samples, cache only on {n_cache_warm}+{n_cache}')
     s = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
     enc = lambda pc6: O.uni3d_encode_pc(pc6, sd_cpu, cfg['G'], cfg['S'], cfg['heads'])
@@ -271,6 +285,8 @@ def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n_full, cfg, cache_feats, n_cach
            'sample': f'samples 1..{n_full - 1} of the same synthetic stream (2 encoder forwards + cache step + residual learning each), '
                      f'value = 1 / median seconds per sample; legs timed separately',
            'legs': legs, 'parallel_info': torch.__config__.parallel_info()}
+    if sim is not None:
+        rec['similarity_check'] = sim
     return rec, torch.cat(finals)
 
 
@@ -430,13 +446,16 @@ def main():
             pa['first_step_samples_within_1e-3'] = int((dd <= 1e-3).sum())
             pa['first_step_max_abs_logit_diff_by_sample'] = [round(float(v), 6) for v in dd]
         out['other_gemm_mode']['prediction_agreement_between_modes'] = pa
+    sim_chk = None
     if rank == 0 and not a.no_similarity:
-        out['similarity'] = similarity_roofline(dev)
+        out['similarity'], sim_chk = similarity_roofline(dev)
     if do_cpu:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
         n = min(a.cpu_samples, n_global) if a.warmup > 0 else a.cpu_samples
         out['cpu_baseline'], cpu_final = cpu_baseline(sd_cpu, text, xyz[:n].cpu(), rgb[:n].cpu(), noise[:n].cpu(), n, cfg, res.get('feats'),
-                                                      a.cpu_cache_samples, a.cpu_cache_warmup)
+                                                      a.cpu_cache_samples, a.cpu_cache_warmup, sim_chk)
+        if 'similarity_check' in out['cpu_baseline']:          # the K = 4096 kernels' outputs (produced before their timed loops) vs the oracle
+            out['similarity']['checked_against_oracle'] = out['cpu_baseline'].pop('similarity_check')
         # without real data the bench reports agreement with the CPU restatement on the synthetic stream - for
         # BOTH GEMM modes, over the head of the first chunk.  Residual learning makes two fp32 arithmetics drift apart sample by
         # sample (the reference against itself: tests/golden/g12), so the per-sample list is the informative part.
