@@ -261,14 +261,17 @@ def cpu_baseline(sd_cpu, text, xyz, rgb, noise, n_full, cfg, cache_feats, n_cach
         t_enc.append(b - a); t_cache.append(c - b)
         if i % 4 == 0:
             log(f'cpu sample {i}: enc {b - a:.2f}s cache {c - b:.2f}s')
-    te, tc = np.array(t_enc[1:]), np.array(t_cache[1:])
+    w0 = 1 if n_full > 1 else 0                     # (a one-sample run has no warm-up to drop)
+    te, tc = np.array(t_enc[w0:]), np.array(t_cache[w0:])
     full = te + tc
-    legs = {'full_step': {'samples': len(full), 'warmup': 1, 'median_s_per_sample': round(float(np.median(full)), 4),
+    legs = {'full_step': {'samples': len(full), 'warmup': w0, 'median_s_per_sample': round(float(np.median(full)), 4),
                           'mean_s_per_sample': round(float(full.mean()), 4), 'value': round(1.0 / float(np.median(full)), 4)},
-            'encoder_only': {'samples': len(te), 'warmup': 1, 'median_s_per_sample': round(float(np.median(te)), 4),
+            'encoder_only': {'samples': len(te), 'warmup': w0, 'median_s_per_sample': round(float(np.median(te)), 4),
                              'mean_s_per_sample': round(float(te.mean()), 4), 'value': round(1.0 / float(np.median(te)), 4),
                              'note': '2 forwards per sample'}}
     if cache_feats is not None and n_cache > 0:
+        n_cache_warm = min(n_cache_warm, max(0, cache_feats.shape[0] - 1))
+        n_cache = min(n_cache, cache_feats.shape[0] - n_cache_warm)
         s2 = O.TtaStream(text, O.TtaConfig(num_modes=cfg['M'], res_learning=cfg['res']))
         ts = []
         for i in range(n_cache_warm + n_cache):

@@ -251,6 +251,30 @@ int ua_gmm_mfma_operand(const float* mu, const float* var, const float* pi, int3
 int ua_gmm_loglik_mfma(const float* x, int32_t B, int32_t K, int32_t M, int32_t D, int32_t terms,
                        float* scores, float* joint, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Residual learning on the matrix cores (Uni_Adapter.py:191-270,444-476; same step as ua_align_forward + ua_align_step,
+ * both contractions with the state as split-f16 MFMA products; csrc/ua_align_mfma.hip).  Envelope: K <= 64, M in
+ * {1,2,4,8,16}, D % 256 == 0 (ua_align_mfma_supported); outside it the VALU entry points above are used.
+ *   ua_align_mfma_prepare : once per sample, after the cache step: forward operand [1/v | -2 mu/v] + row constants
+ *                           (= ua_gmm_mfma_operand) and the transposed operand [mu/v | 1/v] of every 32-feature block.
+ *   ua_align_forward_mfma : from the UNNORMALISED embeddings t = text0 + res (K,D): joint (K,K*M), L (K,K) =
+ *                           likelihood_matrix (:244), U (K,K*M) = sum_d e (mu - e)/v, nrm (K) = |t|.
+ *   ua_align_step_mfma    : loss (:248-253), its gradient through L, grad_e for all rows, and the Adam step
+ *                           (torch.optim.Adam, lr/beta/eps as given, `step` = 1-based step count) on res / adam_m / adam_v,
+ *                           t <- text0 + res, in ONE launch without any cross-workgroup hand-off (the row dot product
+ *                           grad_e . e comes from U).  grad_e (K,D) optional output.
+ * After the last step of a sample the caller refreshes e = t/|t| with ua_text_normalize.                              */
+int ua_align_mfma_supported(int32_t K, int32_t M, int32_t D);
+size_t ua_align_mfma_workspace_bytes(int32_t K, int32_t M, int32_t D);
+int ua_align_mfma_prepare(const float* mu, const float* var, const float* pi, int32_t K, int32_t M, int32_t D, float eps,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int ua_align_forward_mfma(const float* t, int32_t K, int32_t M, int32_t D, const void* workspace, size_t workspace_bytes,
+                          float* L, float* joint, float* U, float* nrm, void* stream);
+int ua_align_step_mfma(const float* L, const float* joint, const float* U, const float* nrm, const float* text0,
+                       float* res, float* adam_m, float* adam_v, float* t, int32_t K, int32_t M, int32_t D, int32_t step,
+                       double lr, double beta1, double beta2, double adam_eps, const void* workspace, size_t workspace_bytes,
+                       float* loss, float* grad_e, void* stream);
+
 /* LayerNorm over the last dim (timm LayerNorm eps 1e-6): rows x cols, cols % 4 == 0, cols<=8192.
  * Columns cols..cols_pad-1 of y are zero-filled (GEMM K padding).                              */
 int ua_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
@@ -285,7 +309,8 @@ int ua_assemble_tokens(const float* tok, const float* pos, const float* cls_toke
  * Composite: the in-order cache replay of a chunk of samples in ONE host call
  * (Uni_Adapter.py:388-521 per sample: clip logits -> predict+fit+fit -> [sample index > 0:
  * res_steps x (alignment forward, loss+grad, backward, Adam)] -> fusion).  Launch orchestration
- * only: identical to calling the entry points above in sequence.
+ * only: identical to calling the entry points above in sequence (with align_mfma: ua_gmm_step_fused,
+ * ua_align_mfma_prepare, res_steps x (ua_align_forward_mfma, ua_align_step_mfma), ua_text_normalize).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t K, M, D;
@@ -299,6 +324,10 @@ typedef struct {
     float  *L, *joint, *grad_ll, *grad_e, *loss;                     /* scratch: (K,K),(K,K,M)x2,(K,D),(1)*/
     float  *inv_var, *row_const;                                     /* scratch: (K,M,D),(K,M)            */
     int32_t *tickets;                                                /* scratch: (K) int32 (ua_align_step) */
+    /* residual learning on the matrix cores (ua_align_*_mfma; used when align_mfma != 0 and the shape is supported): */
+    int32_t align_mfma;                                              /* 0: VALU kernels, 1: MFMA kernels  */
+    float  *t, *U;                                                   /* text0 + res (K,D); scratch (K,K,M) */
+    void   *align_ws; size_t align_ws_bytes;                         /* ua_align_mfma_workspace_bytes      */
 } ua_tta_state;
 
 /* feats (n,2,D): [:,0] encoder output of the sample, [:,1] of its augmented copy.

@@ -479,6 +479,92 @@ def test_alignment_kernels_vs_golden(ua, golden_dir):
     assert torch.equal(torch.sign(gt[big]), torch.sign(ref[big]))
 
 
+def _align_mfma_setup(ua, g):
+    K, M = g['pi'].shape; D = g['mu'].shape[2]
+    assert ua.align_mfma_supported(K, M, D)
+    ws = torch.empty(ua.align_mfma_workspace_bytes(K, M, D), dtype=torch.uint8, device='cuda'); _KEEP.append(ws)
+    mu, var, pi = dev(_t(g['mu'])), dev(_t(g['var'])), dev(_t(g['pi']))
+    ua.call('ua_align_mfma_prepare', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), K, M, D, float(g['eps']), ws.data_ptr(), ws.numel(), ua.stream_ptr())
+    return K, M, D, ws
+
+
+def test_alignment_mfma_kernels_vs_golden(ua, golden_dir):
+    """Residual learning on the matrix cores (csrc/ua_align_mfma.hip) against the reference's own outputs on the g3 state
+    (compute_text_alignment_loss + autograd, Uni_Adapter.py:191-270): likelihood matrix, loss, and - through one Adam step
+    from zero moments, where exp_avg = 0.1 * grad - the gradient w.r.t. the residuals; also grad_e against the VALU chain."""
+    g = _load(golden_dir, 'g3_alignment_scanobjectnn.npz')
+    K, M, D, ws = _align_mfma_setup(ua, g)
+    text0, res = dev(_t(g['text'])), dev(_t(g['res']))
+    t = dev(_t(g['text']) + _t(g['res']))
+    L = torch.empty(K, K, device='cuda'); joint = torch.empty(K, K, M, device='cuda'); U = torch.empty(K, K, M, device='cuda')
+    nrm = torch.empty(K, device='cuda')
+    ua.call('ua_align_forward_mfma', ua.ptr(t), K, M, D, ws.data_ptr(), ws.numel(), ua.ptr(L), ua.ptr(joint), ua.ptr(U), ua.ptr(nrm), ua.stream_ptr())
+    np.testing.assert_allclose(L.cpu().numpy(), g['L'], rtol=0, atol=3e-3)
+    tt = (_t(g['text']) + _t(g['res'])).double()
+    np.testing.assert_allclose(nrm.cpu().double().numpy(), tt.norm(dim=1).numpy(), rtol=1e-6)
+    # U[b,r] = sum_d e (mu - e) / v  (fp64 on the host)
+    e64 = tt / tt.norm(dim=1, keepdim=True)
+    iv = 1.0 / torch.clamp(_t(g['var']).double() + float(g['eps']), min=1e-8)
+    Uref = torch.einsum('bd,kmd->bkm', e64, _t(g['mu']).double() * iv) - torch.einsum('bd,kmd->bkm', e64 * e64, iv)
+    assert (U.cpu().double() - Uref).abs().max().item() <= 3e-3
+    am, av = torch.zeros(K, D, device='cuda'), torch.zeros(K, D, device='cuda')
+    loss = torch.empty(1, device='cuda'); ge = torch.empty(K, D, device='cuda')
+    res2 = res.clone(); t2 = t.clone()
+    ua.call('ua_align_step_mfma', ua.ptr(L), ua.ptr(joint), ua.ptr(U), ua.ptr(nrm), ua.ptr(text0), ua.ptr(res2), ua.ptr(am), ua.ptr(av), ua.ptr(t2),
+            K, M, D, 1, 1e-3, 0.9, 0.999, 1e-8, ws.data_ptr(), ws.numel(), ua.ptr(loss), ua.ptr(ge), ua.stream_ptr())
+    assert abs(loss.item() - float(g['loss'])) < 2e-6
+    ref = _t(g['grad_res']).double()
+    gt = am.cpu().double() * 10.0                                        # exp_avg after the first step = (1 - beta1) * grad
+    assert (gt - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    big = ref.abs() > 1e-3 * ref.abs().max()
+    assert torch.equal(torch.sign(gt[big]), torch.sign(ref[big]))
+    assert torch.equal(t2, text0 + res2)
+    # first Adam step: res moves by -lr * g / (|g| + eps*sqrt(bc2)) ~ -lr * sign(g)
+    step = (res2 - res).cpu().double()
+    assert (step[big] + 1e-3 * torch.sign(ref[big])).abs().max().item() < 2e-5
+    # grad_e of the VALU chain (generic kernels) on the same inputs
+    e = torch.empty(K, D, device='cuda'); n2 = torch.empty(K, device='cuda')
+    ua.call('ua_text_normalize', ua.ptr(text0), ua.ptr(res), K, D, 0.0, ua.ptr(e), ua.ptr(n2), ua.stream_ptr())
+    mu, var, pi = dev(_t(g['mu'])), dev(_t(g['var'])), dev(_t(g['pi']))
+    Lv = torch.empty(K, K, device='cuda'); jv = torch.empty(K, K, M, device='cuda'); gll = torch.empty(K, K, M, device='cuda'); gev = torch.empty(K, D, device='cuda')
+    ua.call('ua_gmm_loglik', ua.ptr(mu), ua.ptr(var), ua.ptr(pi), ua.ptr(e), K, K, M, D, float(g['eps']), ua.ptr(Lv), ua.ptr(jv), None, ua.stream_ptr())
+    ua.call('ua_align_loss', ua.ptr(Lv), ua.ptr(jv), K, M, ua.ptr(loss), ua.ptr(gll), ua.stream_ptr())
+    ua.call('ua_gmm_loglik_bwd', ua.ptr(mu), ua.ptr(var), ua.ptr(e), ua.ptr(gll), K, K, M, D, float(g['eps']), ua.ptr(gev), ua.stream_ptr())
+    assert (ge - gev).abs().max().item() <= 2e-3 * gev.abs().max().item()
+    assert (L - Lv).abs().max().item() <= 3e-3 and (joint - jv).abs().max().item() <= 4e-3
+
+
+@pytest.mark.parametrize('K,M,D', [(15, 8, 1024), (40, 8, 1024), (55, 4, 512), (7, 16, 256), (64, 2, 768)])
+def test_alignment_mfma_ten_steps_vs_oracle(ua, K, M, D):
+    """The 10-step residual-learning loop of one sample (Uni_Adapter.py:444-476) on the matrix cores against the oracle's
+    autograd loop from the same state: residuals, Adam moments, the final normalised text and the last loss."""
+    text, st, g = _stream_state(K, M, D, 30, 21)
+    res0 = 0.002 * torch.randn(K, D, generator=g)
+    a = O.AdamState(0.01 * torch.randn(K, D, generator=g), 1e-4 * torch.rand(K, D, generator=g), step=17)
+    gd = {'mu': st.mu.numpy(), 'var': st.var.numpy(), 'pi': st.pi.numpy(), 'eps': st.epsilon}
+    _, _, _, ws = _align_mfma_setup(ua, gd)
+    text0, res, am, av = dev(text), dev(res0), dev(a.m), dev(a.v)
+    t = dev(text + res0)
+    L = torch.empty(K, K, device='cuda'); joint = torch.empty(K, K, M, device='cuda'); U = torch.empty(K, K, M, device='cuda')
+    nrm = torch.empty(K, device='cuda'); loss = torch.empty(1, device='cuda')
+    for it in range(10):
+        ua.call('ua_align_forward_mfma', ua.ptr(t), K, M, D, ws.data_ptr(), ws.numel(), ua.ptr(L), ua.ptr(joint), ua.ptr(U), ua.ptr(nrm), ua.stream_ptr())
+        ua.call('ua_align_step_mfma', ua.ptr(L), ua.ptr(joint), ua.ptr(U), ua.ptr(nrm), ua.ptr(text0), ua.ptr(res), ua.ptr(am), ua.ptr(av), ua.ptr(t),
+                K, M, D, 18 + it, 1e-3, 0.9, 0.999, 1e-8, ws.data_ptr(), ws.numel(), ua.ptr(loss), None, ua.stream_ptr())
+    ref_res = res0.clone()
+    last_loss, Lref = O.residual_learning(st, text, ref_res, a, 10)
+    d = (res.cpu() - ref_res).abs()
+    # Adam steps are sign-like where |g| >> sqrt(v): an element whose gradient is at round-off level may step the other way
+    # (2e-3 of the elements at most); everything else within 2e-6
+    frac_off = float((d > 2e-6).float().mean())
+    print(f'K={K} M={M} D={D}: max |dres| {d.max().item():.2e}, fraction > 2e-6: {frac_off:.2e}')
+    assert frac_off <= 2e-3 and d.max().item() <= 2.5e-3
+    np.testing.assert_allclose(am.cpu().numpy(), a.m.numpy(), rtol=0, atol=2e-3 * float(a.m.abs().max()))
+    assert torch.equal(t, text0 + res)
+    ua.call('ua_align_forward_mfma', ua.ptr(t), K, M, D, ws.data_ptr(), ws.numel(), ua.ptr(L), ua.ptr(joint), ua.ptr(U), ua.ptr(nrm), ua.stream_ptr())
+    assert (L.cpu() - Lref).abs().max().item() <= 2e-2          # (residuals differ by round-off-level sign flips)
+
+
 def test_residual_adam_matches_oracle(ua):
     g = torch.Generator().manual_seed(9)
     K, D = 12, 512

@@ -107,6 +107,7 @@ class TextResiduals:
         self.v = torch.zeros(K, D, device=dev)
         self.e = torch.empty(K, D, device=dev)
         self.norm = torch.empty(K, device=dev)
+        self.t = self.text0.clone()                 # text0 + res, unnormalised (the MFMA residual kernels work on it)
         self.step = 0
         lib.call('ua_text_normalize', lib.ptr(self.text0), lib.ptr(self.res), K, D, 0.0, lib.ptr(self.e), lib.ptr(self.norm),
                  lib.stream_ptr())
@@ -118,7 +119,7 @@ class TtaEngine:
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
                  log_alignment_every=0, dist_group=None, composite=True, overlap=False, replay_mode=None,
-                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False, emulated_rank=None):
+                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False, emulated_rank=None, align_path=None):
         self.model = model
         self.composite = bool(composite) and not log_alignment_every
         # overlap=True: the in-order cache replay of chunk c runs on a second HIP stream while the
@@ -183,9 +184,17 @@ class TtaEngine:
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
         self.fh, self.fa = e(1, D), e(1, D)
         self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
+        # UA_ALIGN_PATH=mfma runs the residual loop on the matrix cores (csrc/ua_align_mfma.hip) when the shape is inside its
+        # envelope.  Opt-in: at K = 40 the two GEMMs are 0.05 GFLOP - the step is bound by kernel floors and per-CU L2
+        # bandwidth, not arithmetic, and the VALU kernels (work spread over 160-400 workgroups) are faster
+        self.align_mfma = (self.res_learning and lib.align_mfma_supported(K, M, D)
+                           and (align_path or os.environ.get('UA_ALIGN_PATH', 'valu')) == 'mfma')
         if self.res_learning:               # K x K work arrays of the residual loop (1 GB each at K = 4096, M = 16: only when used)
             self.L, self.joint, self.gll, self.ge, self.loss = e(K, K), e(K, K, M), e(K, K, M), e(K, D), e(1)
             self.inv_var, self.row_const = e(K, M, D), e(K, M)
+            if self.align_mfma:
+                self.U = e(K, K, M)
+                self.align_ws = torch.empty(lib.align_mfma_workspace_bytes(K, M, D), dtype=torch.uint8, device=dev)
         else:
             self.L = self.joint = self.gll = self.ge = self.inv_var = self.row_const = None
             self.loss = e(1)
@@ -212,6 +221,10 @@ class TtaEngine:
             s.L, s.joint, s.grad_ll, s.grad_e = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge))
             s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
         s.tickets = self.tickets.data_ptr()
+        if self.res_learning and self.align_mfma:
+            s.align_mfma = 1
+            s.t, s.U = r.t.data_ptr(), self.U.data_ptr()
+            s.align_ws, s.align_ws_bytes = self.align_ws.data_ptr(), self.align_ws.numel()
         return s
 
     # -- encoder part: this rank's share of the chunk -------------------------------------
@@ -264,7 +277,23 @@ class TtaEngine:
         lib.call('ua_clip_logits', lib.ptr(feat_aug), lib.ptr(text), K, D, LOGIT_SCALE, 2, lib.ptr(self.fa), None, None, None,
                  None, st)                                                                   # :424,:429
         mdl.step_fused(self.fh, self.fh, self.fa, self.prob, scores=self.dz)                 # :416,:417,:430
-        if self.i > 0 and self.res_learning:                                                 # :444-476
+        if self.i > 0 and self.res_learning and self.align_mfma:                             # :444-476 on the matrix cores
+            r, ws = self.residuals, self.align_ws
+            lib.call('ua_align_mfma_prepare', lib.ptr(mdl.mu), lib.ptr(mdl.var), lib.ptr(mdl.pi), K, M, D, mdl.epsilon, ws.data_ptr(), ws.numel(), st)
+            for _ in range(RES_STEPS):
+                lib.call('ua_align_forward_mfma', lib.ptr(r.t), K, M, D, ws.data_ptr(), ws.numel(), lib.ptr(self.L), lib.ptr(self.joint),
+                         lib.ptr(self.U), lib.ptr(r.norm), st)
+                r.step += 1
+                lib.call('ua_align_step_mfma', lib.ptr(self.L), lib.ptr(self.joint), lib.ptr(self.U), lib.ptr(r.norm), lib.ptr(r.text0),
+                         lib.ptr(r.res), lib.ptr(r.m), lib.ptr(r.v), lib.ptr(r.t), K, M, D, r.step, RES_LR, 0.9, 0.999, 1e-8,
+                         ws.data_ptr(), ws.numel(), lib.ptr(self.loss), None, st)
+            lib.call('ua_text_normalize', lib.ptr(r.text0), lib.ptr(r.res), K, D, 0.0, lib.ptr(r.e), lib.ptr(r.norm), st)
+            if self.log_every and self.i % self.log_every == 0:                              # :480-485 (the 11th loss evaluation)
+                lib.call('ua_align_forward_mfma', lib.ptr(r.t), K, M, D, ws.data_ptr(), ws.numel(), lib.ptr(self.L), lib.ptr(self.joint),
+                         lib.ptr(self.U), lib.ptr(r.norm), st)
+                lib.call('ua_align_loss', lib.ptr(self.L), lib.ptr(self.joint), K, M, lib.ptr(self.loss), None, st)
+                self.last_loss = self.loss.clone()
+        elif self.i > 0 and self.res_learning:                                               # :444-476
             r = self.residuals
             lib.call('ua_gmm_prepare_alignment', lib.ptr(mdl.var), lib.ptr(mdl.pi), K, M, D, mdl.epsilon, lib.ptr(self.inv_var),
                      lib.ptr(self.row_const), st)
@@ -507,6 +536,7 @@ class TtaEngine:
             for key, t in (('res', r.res), ('m', r.m), ('v', r.v)):
                 lib.call('ua_vec_merge', lib.ptr(s0[key]), g + 4 * o[key], W, stride, K * D, 1.0 / W, lib.ptr(t), st)
             lib.call('ua_text_normalize', lib.ptr(r.text0), lib.ptr(r.res), K, D, 0.0, lib.ptr(r.e), lib.ptr(r.norm), st)
+            torch.add(r.text0, r.res, out=r.t)
             starts = [sum(counts[:q]) for q in range(W)]
             r.step += max(RES_STEPS * (counts[q] - (1 if self.i + starts[q] == 0 and counts[q] else 0)) for q in range(W))
         out = gathered[:, o['out']:o['out'] + per * (K + 2)].view(W, per, K + 2)
@@ -553,6 +583,7 @@ class TtaEngine:
             for dst, key in ((r.res, 'res'), (r.m, 'adam_m'), (r.v, 'adam_v'), (r.e, 'e'), (r.norm, 'norm')):
                 dst.copy_(sd[key].to(dst.device, dst.dtype))
             r.step = int(sd['adam_step'])
+            r.t.copy_(r.text0 + r.res)
         self.i, self.count = int(sd['i']), int(sd['count'])
         self.correct.copy_(sd['correct'].to(self.correct.device, self.correct.dtype))
 

@@ -598,71 +598,16 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
 // =============================================================================================
 namespace {
 
-__device__ __forceinline__ float pow2_scale(float amax) {
-    // largest power of two s with amax * s <= 30000 (fp16 max 65504), clamped to [2^-14, 2^14]
-    if (!(amax > 0.f)) return 1.f;
-    int e;
-    frexpf(30000.0f / amax, &e);                       // 30000/amax = f * 2^e, f in [0.5, 1)
-    e = max(-14, min(14, e - 1));
-    return ldexpf(1.0f, e);
-}
-
-// Contraction layout: K-tile 2i holds features d = 32i..32i+31 of the first part (x^2 | 1/v), K-tile 2i+1 the same
-// features of the second part (x | -2 mu/v), so the running sum of a GEMM accumulator follows
-// sum_{d' < d} ((x - mu)^2 - mu^2)/v instead of first climbing to sum x^2/v (~5e3) and then coming back down: the fp32
-// roundings of the accumulate chain happen at about half the magnitude.
-__device__ __forceinline__ int sim_col(int part, int d) { return (d >> 5) * 64 + part * 32 + (d & 31); }
-
-__device__ __forceinline__ void store_split4(unsigned char* row, int c, float4 v, float s) {
-    ua::f16x4 hi, lo;
-    ua::split4(v, s, hi, lo);
-    unsigned char* q = row + ua::split_col_off(c);
-    *reinterpret_cast<ua::f16x4*>(q) = hi;
-    *reinterpret_cast<ua::f16x4*>(q + 64) = lo;
-}
+using ua::pow2_scale; using ua::sim_col; using ua::store_split4;
 
 // one wave per state row n = k*M + m; block = 4 waves
 template <int VEC>
 __global__ void __launch_bounds__(256)
 gmm_operand_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ pi, int KM, float eps,
                    unsigned char* __restrict__ Wop, float* __restrict__ rc, float* __restrict__ colscale) {
-    constexpr int D = 256 * VEC;
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= KM) return;                                                     // wave-uniform
-    const float4* pm = reinterpret_cast<const float4*>(mu + (size_t)n * D);
-    const float4* pv = reinterpret_cast<const float4*>(var + (size_t)n * D);
-    float4 a[VEC], b[VEC];
-    double ld = 0.0, mq = 0.0;
-    float amax = 0.f;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const float4 m4 = pm[v * 64 + lane], v4 = pv[v * 64 + lane];
-#define UA_OP(F)                                                                           \
-        {                                                                                  \
-            const float rv = fmaxf(v4.F + eps, 1e-8f);                 /* dota_mixture.py:117-119 */ \
-            const float iv = 1.0f / rv;                                                    \
-            ld += (double)logf(rv);                                                        \
-            mq += (double)((m4.F * m4.F) * iv);                                            \
-            a[v].F = iv; b[v].F = (-2.0f * m4.F) * iv;                                     \
-            amax = fmaxf(amax, fmaxf(iv, fabsf(b[v].F)));                                  \
-        }
-        UA_OP(x) UA_OP(y) UA_OP(z) UA_OP(w)
-#undef UA_OP
-    }
-    ld = ua::wave_sum(ld); mq = ua::wave_sum(mq);
-    amax = ua::wave_max(amax);
-    const float s = pow2_scale(amax);
-    unsigned char* row = Wop + (size_t)n * (2 * D) * 4;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        store_split4(row, sim_col(0, c), a[v], s);
-        store_split4(row, sim_col(1, c), b[v], s);
-    }
-    if (lane == 0) {
-        rc[n] = (float)((double)logf(pi[n] + 1e-10f) - 0.5 * ld - 0.5 * mq);
-        colscale[n] = -0.5f / s;
-    }
+    ua::gmm_operand_row<VEC>(mu, var, pi, n, eps, lane, Wop, rc, colscale);
 }
 
 // one wave per query row b: A row = [x^2 | x] (split), row_scale[b] = 1/s_b
@@ -784,23 +729,7 @@ gmm_loglik_mfma_small_kernel(const unsigned char* __restrict__ Aop, const unsign
     }
 }
 
-inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-struct MfmaWs { unsigned char* Wop; float* rc; float* colscale; unsigned char* Aop; float* row_scale; float* joint; size_t total; };
-
-inline MfmaWs mfma_ws_layout(unsigned char* base, int B, int K, int M, int D, bool need_joint) {
-    MfmaWs w{};
-    size_t o = 0;
-    const size_t KM = (size_t)K * M;
-    w.Wop = base + o; o += align256(KM * 2 * D * 4);
-    w.rc = reinterpret_cast<float*>(base + o); o += align256(KM * 4);
-    w.colscale = reinterpret_cast<float*>(base + o); o += align256(KM * 4);
-    w.Aop = base + o; o += align256((size_t)B * 2 * D * 4);
-    w.row_scale = reinterpret_cast<float*>(base + o); o += align256((size_t)B * 4);
-    if (need_joint) { w.joint = reinterpret_cast<float*>(base + o); o += align256((size_t)B * KM * 4); }
-    w.total = o;
-    return w;
-}
+using ua::MfmaWs; using ua::mfma_ws_layout;
 
 inline bool lse_fusable(int M) { return M == 4 || M == 8 || M == 16; }     // both paths fuse these (the small path also M = 1, 2)
 

@@ -636,7 +636,8 @@ align_step_kernel(AlignStepArgs a) {
     }
     ST_MARK(1);
     // ---- loss statistics: the code of align_loss_kernel (ua_align_common.h), L staged in LDS ----
-    const ua::AlignStats stt = ua::align_stats(a.L, Ls, K, P, s1, s2, dg, sd, sf, &s_arg);
+    double* sc = &s_acc[0][0];                              // (s_acc is first written after the statistics)
+    const ua::AlignStats stt = ua::align_stats(a.L, Ls, K, P, s1, s2, dg, sd, sf, &s_arg, sc);
     if (b == 0 && c == 0 && tid == 0 && a.loss_out) *a.loss_out = (float)(-stt.tot / (double)K);
     const float mx = stt.mx, corr = stt.corr;
     const int amax = stt.amax;

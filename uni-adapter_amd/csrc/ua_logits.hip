@@ -305,7 +305,8 @@ align_loss_kernel(const float* __restrict__ L, const float* __restrict__ joint, 
     float* s2 = s1 + K;              // col sums
     float* dg = s2 + K;              // diagonal
     const int n = K * K, tid = threadIdx.x, nt = blockDim.x;
-    const ua::AlignStats st = ua::align_stats(L, nullptr, K, P, s1, s2, dg, sd, sf, &s_arg);
+    __shared__ double sc[16 * 64];
+    const ua::AlignStats st = ua::align_stats(L, nullptr, K, P, s1, s2, dg, sd, sf, &s_arg, sc);
     if (tid == 0 && loss_out) *loss_out = (float)(-st.tot / (double)K);             // :253
     if (!grad_ll) return;
     const float mx = st.mx, corr = st.corr;

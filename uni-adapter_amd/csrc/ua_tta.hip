@@ -25,12 +25,26 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
         if ((rc = ua_clip_logits_pair(f, fa, text, K, D, s->logit_scale, s->fhat, s->faug, s->clip_logits, s->prob,
                                       stream))) return rc;               // :406, :424, :429
         const bool learn = s->res_learning && sample_index0 + j > 0;
-        if (learn) {   // cache step + the per-sample constants of the residual loop (1/v, row constants) in one launch
+        const bool mfma = learn && s->align_mfma && s->t && s->U && s->align_ws && ua_align_mfma_supported(K, M, D);
+        if (mfma) {    // residual learning on the matrix cores (csrc/ua_align_mfma.hip)
+            if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
+                                        s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;                // :416,:417,:430
+            if ((rc = ua_align_mfma_prepare(s->mu, s->var, s->pi, K, M, D, s->eps, s->align_ws, s->align_ws_bytes, stream))) return rc;
+            for (int it = 0; it < s->res_steps; ++it) {                                                            // :444-476
+                if ((rc = ua_align_forward_mfma(s->t, K, M, D, s->align_ws, s->align_ws_bytes, s->L, s->joint, s->U, s->norm, stream))) return rc;
+                ++adam_step;
+                if (adam_step > 0x7fffffff) return UA_EINVAL;
+                if ((rc = ua_align_step_mfma(s->L, s->joint, s->U, s->norm, s->text0, s->res, s->adam_m, s->adam_v, s->t, K, M, D,
+                                             (int32_t)adam_step, s->lr, s->beta1, s->beta2, s->adam_eps, s->align_ws, s->align_ws_bytes,
+                                             s->loss, nullptr, stream))) return rc;
+            }
+            if ((rc = ua_text_normalize(s->text0, s->res, K, D, 0.0f, s->e, s->norm, stream))) return rc;             // e = t/|t| for :388-393
+        } else if (learn) {   // cache step + the per-sample constants of the residual loop (1/v, row constants) in one launch
             if ((rc = ua_gmm_step_fused_prepare(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
                                                 s->prob, s->dota_scores, K, M, D, s->eps, s->inv_var, s->row_const, stream))) return rc;
         } else if ((rc = ua_gmm_step_fused(s->mu, s->var, s->pi, s->c, s->class_counts, s->fhat, 1, s->fhat, s->faug,
                                            s->prob, s->dota_scores, K, M, D, s->eps, stream))) return rc;   // :416,:417,:430
-        if (learn) {                                                            // :444-476
+        if (learn && !mfma) {                                                   // :444-476
             for (int it = 0; it < s->res_steps; ++it) {
                 if ((rc = ua_align_forward(s->mu, s->inv_var, s->row_const, s->e, K, K, M, D, s->L, s->joint, stream))) return rc;
                 ++adam_step;

@@ -42,7 +42,8 @@ class TtaState(C.Structure):
                 ('res', _p), ('adam_m', _p), ('adam_v', _p), ('e', _p), ('norm', _p),
                 ('fhat', _p), ('faug', _p), ('clip_logits', _p), ('prob', _p), ('dota_scores', _p),
                 ('L', _p), ('joint', _p), ('grad_ll', _p), ('grad_e', _p), ('loss', _p),
-                ('inv_var', _p), ('row_const', _p), ('tickets', _p)]
+                ('inv_var', _p), ('row_const', _p), ('tickets', _p),
+                ('align_mfma', _i32), ('t', _p), ('U', _p), ('align_ws', _p), ('align_ws_bytes', C.c_size_t)]
 
 
 # name -> argtypes, exactly the declarations of include/uniadapter.h
@@ -91,6 +92,9 @@ SIGNATURES = {
     'ua_cls_max_concat': [_p, _p, _i32, _i32, _i32, _p],
     'ua_tta_chunk': [C.POINTER(TtaState), _p, _p, _i32, _i64, _i64, _p, _p, _p, _p],
     'ua_gmm_mfma_operand': [_p, _p, _p, _i32, _i32, _i32, _f, _p, C.c_size_t, _p],
+    'ua_align_mfma_prepare': [_p, _p, _p, _i32, _i32, _i32, _f, _p, C.c_size_t, _p],
+    'ua_align_forward_mfma': [_p, _i32, _i32, _i32, _p, C.c_size_t, _p, _p, _p, _p, _p],
+    'ua_align_step_mfma': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _d, _d, _d, _d, _p, C.c_size_t, _p, _p, _p],
     'ua_gmm_loglik_mfma': [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, C.c_size_t, _p],
 }
 
@@ -100,6 +104,10 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = C.c_int
 _lib.ua_gmm_loglik_mfma_workspace_bytes.restype = C.c_size_t
 _lib.ua_gmm_loglik_mfma_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
+_lib.ua_align_mfma_workspace_bytes.restype = C.c_size_t
+_lib.ua_align_mfma_workspace_bytes.argtypes = [_i32, _i32, _i32]
+_lib.ua_align_mfma_supported.restype = C.c_int
+_lib.ua_align_mfma_supported.argtypes = [_i32, _i32, _i32]
 _lib.ua_version.restype = C.c_int
 _lib.ua_strerror.restype = C.c_char_p
 _lib.ua_strerror.argtypes = [C.c_int]
@@ -107,6 +115,14 @@ _lib.ua_strerror.argtypes = [C.c_int]
 
 def version():
     return _lib.ua_version()
+
+
+def align_mfma_supported(K, M, D):
+    return bool(_lib.ua_align_mfma_supported(K, M, D))
+
+
+def align_mfma_workspace_bytes(K, M, D):
+    return int(_lib.ua_align_mfma_workspace_bytes(K, M, D))
 
 
 def mfma_workspace_bytes(B, K, M, D):
