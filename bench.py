@@ -347,6 +347,10 @@ def main():
                 s = slice(i * n_global, (i + 1) * n_global)
             return eng.process_chunk(xyz[s], rgb[s], None, noise[s])
 
+        if world > 1 and eng.replay_mode == 'owner':
+            # rho (replay cost / encoder cost per sample) measured here instead of a constant calibrated elsewhere; rank 0's value everywhere
+            rho = eng.calibrate_replay_cost(xyz[:8], rgb[:8], noise[:8])
+            log(f'[{precision}] owner mode: measured replay/encoder cost ratio {rho:.3f}')
         log(f'[{precision}] model + stream resident; warm-up')
         first = None
         for i in range(a.warmup):

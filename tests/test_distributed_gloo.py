@@ -317,3 +317,25 @@ def test_share_rules_partition_every_step():
             edges = [(min(r * per, K), min(min(r * per, K) + per, K)) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == K
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+
+
+def _worker_ratio(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import uni_adapter_amd  # noqa: F401
+    from uni_adapter_amd.stream import agree_on_ratio, shard_counts
+    rho = agree_on_ratio(0.3 + 0.05 * rank, 2.0 + 0.1 * rank, world)            # every rank measures something slightly different
+    torch.save({'rho': rho, 'counts': shard_counts(62, world, rho)}, out + f'.r{rank}')
+    dist.destroy_process_group()
+
+
+def test_measured_cost_ratio_is_rank_zeros_on_every_rank(tmp_path):
+    """'owner' mode cuts every chunk with shard_counts(n, W, rho): rho is measured in the warm-up (TtaEngine.calibrate_replay_cost)
+    and must be bit-identical on all ranks - rank 0's measurement is broadcast."""
+    out = str(tmp_path / 'ratio')
+    mp.spawn(_worker_ratio, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = [torch.load(out + f'.r{r}', weights_only=True) for r in range(3)]
+    assert got[0]['rho'] == got[1]['rho'] == got[2]['rho'] == 0.3 / 2.0
+    assert got[0]['counts'] == got[1]['counts'] == got[2]['counts'] and sum(got[0]['counts']) == 62

@@ -30,12 +30,12 @@ class FeatureFeeder(torch.nn.Module):
         return out.contiguous()
 
 
-def _run_hip_stream(g, n, chunk, res_learning=True, with_targets=True):
+def _run_hip_stream(g, n, chunk, res_learning=True, with_targets=True, align_path=None):
     from uni_adapter_amd.Uni_Adapter import TtaEngine
     text = torch.from_numpy(g['text'])
     feats = torch.stack([torch.from_numpy(g['feat'][:n]), torch.from_numpy(g['feat_aug'][:n])], 1).cuda()
     eng = TtaEngine(FeatureFeeder(feats), text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, int(g['M']), res_learning=res_learning,
-                    chunk=chunk)
+                    chunk=chunk, align_path=align_path)
     finals, preds = [], []
     tgt = torch.from_numpy(g['labels'][:n]).int()
     for s0 in range(0, n, chunk):
@@ -129,6 +129,32 @@ def test_long_stream_against_the_references_own_spread(golden_dir):
     acc = float((pred == g['labels']).mean())
     assert min(accs) - 0.05 <= acc <= max(accs) + 0.05, (acc, accs)
     assert abs(eng.accuracy()['acc1'] - 100.0 * acc) < 1e-9
+
+
+def test_mfma_alignment_path_through_the_engine(golden_dir):
+    """TtaEngine(align_path='mfma'): the residual loop on the matrix cores (csrc/ua_align_mfma.hip) driven by the composite
+    replay, on the first 64 samples of the long stream: within 1e-3 of the reference while its own runs agree, identical
+    predictions there, never farther from the nearest reference run than twice the runs' diameter, and the per-kernel
+    (non-composite) path gives bit-identical results."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = _load(golden_dir, 'g12_long_stream_modelnet40.npz')
+    n = 64
+    final, pred, eng = _run_hip_stream(g, n, 16, align_path='mfma')
+    assert eng.align_mfma
+    V = [str(v) for v in g['variants']]
+    T = {v: g['final_' + v][:n].astype(np.float64) for v in V}
+    P = {v: g['pred_' + v][:n] for v in V}
+    T['hip'], P['hip'] = final, pred
+    h = _spread_stats(T, P, 'hip', V)
+    calm = int(np.argmax(h['diam'] > 1e-3))
+    assert calm >= 3 and (np.abs(final - T['a']).max(1)[:calm] <= 1e-3).all() and np.array_equal(pred[:calm], P['a'][:calm])
+    assert h['over_2x'] == 0
+    # composite entry == per-kernel calls on this path too
+    text = torch.from_numpy(g['text'])
+    feats = torch.stack([torch.from_numpy(g['feat'][:8]), torch.from_numpy(g['feat_aug'][:8])], 1).cuda()
+    e2 = TtaEngine(FeatureFeeder(feats), text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, int(g['M']), chunk=8, composite=False, align_path='mfma')
+    f2 = e2.process_chunk(torch.zeros(8, 8, 3), torch.ones(8, 8, 3))[0].cpu().double().numpy()
+    assert np.array_equal(f2, final[:8])
 
 
 def test_long_stream_without_residual_learning_holds_the_1e_3_bar(golden_dir):

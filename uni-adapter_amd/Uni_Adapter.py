@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import lib
 from .dota_mixture import DOTA_mix
-from .stream import (REPLAY_COST_RATIO, broadcast_from_owner, gather_deltas, gather_feature_blocks, gather_features, shard_block,
+from .stream import (REPLAY_COST_RATIO, agree_on_ratio, broadcast_from_owner, gather_deltas, gather_feature_blocks, gather_features, shard_block,
                      shard_counts, shard_indices)
 
 LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
@@ -226,6 +226,45 @@ class TtaEngine:
             s.t, s.U = r.t.data_ptr(), self.U.data_ptr()
             s.align_ws, s.align_ws_bytes = self.align_ws.data_ptr(), self.align_ws.numel()
         return s
+
+    # -- 'owner' mode: measure rho = replay cost / encoder cost on this machine instead of assuming it ----------------
+    @torch.no_grad()
+    def calibrate_replay_cost(self, pc, rgb, noise, reps=2):
+        """Times the encoder on the given few samples (every rank) and the in-order replay of their features (on a scratch
+        copy of the adaptation state, which is restored), and sets `replay_cost_ratio` to rank 0's ratio on all ranks.
+        Call once before the stream; a no-op unless W > 1 in 'owner' mode.  Returns the ratio."""
+        if not (self.world > 1 and self.replay_mode == 'owner'):
+            return self.replay_cost_ratio
+        import ctypes
+        pc, rgb, noise = (t.to(self.dev, torch.float32) for t in (pc, rgb, noise))
+        n = pc.shape[0]
+        clouds = torch.cat((torch.cat((pc, rgb), -1), torch.cat((pc + NOISE_STD * noise, rgb), -1)), 0)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        feats = self.model.encode_pc(clouds)                                   # warm (allocations, code objects)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(reps):
+            feats = self.model.encode_pc(clouds)
+        e1.record(); torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / reps / n
+        rep_ms = 0.0
+        if self.rank == 0:
+            feats2 = torch.stack((feats[:n], feats[n:]), 1).contiguous()
+            saved = self.state_dict()
+            final = torch.empty(n, self.K, device=self.dev); preds = torch.empty(n, dtype=torch.int32, device=self.dev)
+            st = torch.cuda.current_stream().cuda_stream
+            run = lambda: lib.call('ua_tta_chunk', ctypes.byref(self._state), lib.ptr(feats2), None, n, 1, self.residuals.step if self.res_learning else 0,
+                                   lib.ptr(final), None, lib.ptr(preds, torch.int32), st)
+            run()
+            r0, r1 = ev(), ev()
+            r0.record()
+            for _ in range(reps):
+                run()
+            r1.record(); torch.cuda.synchronize()
+            rep_ms = r0.elapsed_time(r1) / reps / n
+            self.load_state_dict(saved)
+        self.replay_cost_ratio = agree_on_ratio(rep_ms, enc_ms, self.world, self.group, self.dev)
+        return self.replay_cost_ratio
 
     # -- encoder part: this rank's share of the chunk -------------------------------------
     def encode_chunk(self, pc, rgb, noise):
@@ -721,6 +760,10 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
             return
         pc, rgb, t = torch.cat(buf_pc), torch.cat(buf_rgb), torch.cat(buf_t)
         noise = torch.cat([noise_fn(seen + j, pc[j:j + 1]) for j in range(pc.shape[0])]) if noise_fn else None
+        if seen == 0 and eng.world > 1 and eng.replay_mode == 'owner':      # measure the replay / encoder cost ratio on the first clouds
+            m = min(8, pc.shape[0])
+            rho = eng.calibrate_replay_cost(pc[:m], rgb[:m], noise[:m] if noise is not None else torch.randn(m, pc.shape[1], 3))
+            logging.info(f"owner replay mode: measured replay/encoder cost ratio {rho:.3f}")
         eng.process_chunk(pc, rgb, t, noise)
         seen += pc.shape[0]
         buf_pc.clear(); buf_rgb.clear(); buf_t.clear()

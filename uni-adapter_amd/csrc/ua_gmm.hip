@@ -18,6 +18,7 @@
 #include "ua_common.h"
 #include "ua_align_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -875,7 +876,10 @@ static int step_fused_impl(float* mu, float* var, float* pi, float* c, float* cl
     return dispatch_vec(D, [&](auto vec) {
         constexpr int VEC = decltype(vec)::value;
         if constexpr (VEC <= 4) {
-            hipLaunchKernelGGL(gmm_step1_kernel<VEC>, dim3(K < 256 ? K : 256), dim3(M * 64), 0, ua::as_stream(stream), a);
+            // 119 VGPRs: 4 waves per SIMD = one 16-wave workgroup per CU, or two of <= 8 waves (M <= 8): fill both slots
+            // (K = 1156, M = 8: 54.0 -> 46.0 us; a 64-VGPR build that fits two 16-wave workgroups spills and is slower: 0.32 vs 0.40)
+            const int cap = M <= 8 ? 512 : 256;
+            hipLaunchKernelGGL(gmm_step1_kernel<VEC>, dim3(K < cap ? K : cap), dim3(M * 64), 0, ua::as_stream(stream), a);
             UA_LAUNCH_CHECK();
         }
         return UA_OK;

@@ -39,7 +39,19 @@ Device-agnostic on purpose (no HIP calls), so the N>1 logic is covered by world_
 """
 import torch
 
-REPLAY_COST_RATIO = 0.15        # rho: see above
+REPLAY_COST_RATIO = 0.15        # rho: see above; a fallback - engines calibrate it from their warm-up (agree_on_ratio)
+
+
+def agree_on_ratio(replay_ms_per_sample, encode_ms_per_sample, world, group=None, device=None):
+    """'owner' mode: rho = (replay cost per sample on rank 0) / (encoder cost per sample), measured by every rank in its
+    warm-up and made identical everywhere by taking RANK 0's value (one broadcast of a float64 - every rank must cut the
+    chunks with the same shard_counts).  Clamped to [0, 2]."""
+    rho = float(replay_ms_per_sample) / max(float(encode_ms_per_sample), 1e-9)
+    if world > 1:
+        t = torch.tensor([rho], dtype=torch.float64, device=device if device is not None and torch.distributed.get_backend(group) != 'gloo' else 'cpu')
+        torch.distributed.broadcast(t, src=0, group=group)
+        rho = float(t.item())
+    return min(max(rho, 0.0), 2.0)
 
 
 def shard_counts(n, world, rho=REPLAY_COST_RATIO):
