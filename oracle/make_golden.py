@@ -3,7 +3,7 @@
 
 TEST INFRASTRUCTURE ONLY - run in the build container (the GPU box has no /root/reference):
 
-    python oracle/make_golden.py [--skip-long | --only-long]     # writes tests/golden/
+    python oracle/make_golden.py [--skip-long | --only-long | --only-extras]     # writes tests/golden/
                                         (the g12 long streams take ~20 minutes; --only-long regenerates just those)
 
 What executes reference code here (nothing is copied into the repo; only inputs/outputs are
@@ -325,12 +325,100 @@ def long_streams():
               'pred agreement', float((out['pred_' + v] == out['pred_a']).mean()))
 
 
+# ---- extras (round 2): branches of the reference that its CLI does not reach but its code defines -----------------------
+def extras():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    # G10b: dota.DOTA(streaming_update_Sigma=False) - the covariances stay at sigma*I, only means and counts move (dota.py:54-58)
+    ns10 = {'torch': torch, 'nn': nn}
+    _exec_defs(os.path.join(REF, 'dota.py'), ['DOTA'], ns10)
+    K10, D10, n10 = 8, 256, 10
+    g10 = torch.Generator().manual_seed(33)
+    text10 = torch.nn.functional.normalize(torch.randn(K10, D10, generator=g10), dim=1)
+    ref10 = ns10['DOTA']({'epsilon': 1e-4, 'sigma': 1e-4}, D10, K10, text10.T.clone(), streaming_update_Sigma=False)
+    lab10 = torch.randint(0, K10, (n10,), generator=g10)
+    X10 = torch.nn.functional.normalize(text10[lab10] + 0.35 * torch.randn(n10, D10, generator=g10), dim=1)
+    Y10 = torch.softmax(100.0 * X10 @ text10.T, dim=1)
+    sc10 = []
+    for i in range(n10):
+        sc10.append(ref10.predict(X10[i:i + 1].half()).float())
+        ref10.fit(X10[i:i + 1], Y10[i:i + 1]); ref10.update()
+    np.savez_compressed(os.path.join(OUT, 'g10b_dota_mean_only.npz'), text=text10.numpy(), X=X10.numpy(), Y=Y10.numpy(), eps=np.float64(1e-4),
+                        sigma=np.float64(1e-4), scores=torch.cat(sc10).numpy(), mu=ref10.mu.numpy(), c=ref10.c.numpy(),
+                        Sigma0=ref10.Sigma[0].numpy(), Lambda=ref10.Lambda.float().numpy())
+    print('g10b dota mean-only', torch.cat(sc10).shape)
+    # G11b: the exact-inverse refinement of the cluster cache (compute_cache_logits_old, Uni_Adapter.py:159-189 with
+    #       math_utils.online_value_refinement_old) on the g11 stream
+    mu11 = _load_source_module('ref_math_utils', os.path.join(REF, 'utils', 'math_utils.py'))
+    ns11 = {'torch': torch, 'F': F, 'np': np, 'math_utils': mu11}
+    _exec_defs(os.path.join(REF, 'Uni_Adapter.py'), ['softmax_entropy', 'get_entropy', 'update_cache', 'compute_cache_logits_old'], ns11)
+    K11, D11, n11, cap11 = 6, 256, 40, 3
+    g11 = torch.Generator().manual_seed(77)
+    text11 = torch.nn.functional.normalize(torch.randn(K11, D11, generator=g11), dim=1)
+    lab11 = torch.randint(0, K11, (n11,), generator=g11)
+    feats11 = text11[lab11] + 0.9 * torch.randn(n11, D11, generator=g11) / 16
+    hp11 = {'shot_capacity': cap11, 'beta': 150, 'threshold': 0.5, 'lambda_reg': 0.11}
+    cw11 = text11.T.contiguous()
+    cache11 = {}
+    fin11, z211 = [], []
+    for i in range(n11):                                                       # loop body :406, :541-574 with use_new_approximation False
+        pcf = feats11[i:i + 1] / feats11[i:i + 1].norm(dim=-1, keepdim=True)
+        cl = 100. * pcf @ cw11
+        loss = ns11['softmax_entropy'](cl); pm = cl.softmax(1)
+        pred = int(cl.topk(1, dim=1)[1].t()[0])
+        pe = torch.tensor(ns11['get_entropy'](loss, cw11))
+        ns11['update_cache'](cache11, pred, [pcf, loss, pe, pm], shot_capacity=cap11, clip_weights=cw11, beta=150)
+        fl = cl.clone() / 100.0
+        p1 = torch.softmax(fl, dim=1); e1 = ns11['softmax_entropy'](p1, False)
+        fl2 = ns11['compute_cache_logits_old'](pcf, cache11, cw11, hp11)
+        p2 = torch.softmax(fl2, dim=1); e2 = ns11['softmax_entropy'](p2, False)
+        fin11.append((1 / e1).reshape(-1, 1) * p1 + (1 / e2).reshape(-1, 1) * p2); z211.append(fl2)
+    np.savez_compressed(os.path.join(OUT, 'g11b_cluster_cache_exact_inverse.npz'), text=text11.numpy(), feats=feats11.numpy(), cap=np.int64(cap11),
+                        beta=np.float64(150), threshold=np.float64(0.5), lambda_reg=np.float64(0.11), finals=torch.cat(fin11).numpy(),
+                        cache_logits=torch.cat(z211).numpy())
+    print('g11b cluster cache, exact inverse', torch.cat(z211).shape)
+    # G13: attention maps by the reference's own hook arithmetic for EVA-style blocks (extract_attention.py:115-160: separate
+    #      q/k/v projections, heads, scale, softmax) - the in-tree description of the third-party timm EvaAttention
+    import logging
+    import typing
+    ns13 = {'torch': torch, 'nn': nn, 'F': F, 'np': np, 'logging': logging, 'Dict': typing.Dict, 'List': typing.List, 'Tuple': typing.Tuple,
+            'Optional': typing.Optional, 'logger': logging.getLogger('g13')}
+    _exec_defs(os.path.join(REF, 'extract_attention.py'), ['AttentionExtractor'], ns13)
+    ext = object.__new__(ns13['AttentionExtractor'])
+    ext.attention_maps = {}
+    hook = ext._attention_hook_with_save(0)
+    C13, H13, G13, B13 = 128, 2, 128, 2
+    sd13 = O.make_uni3d_state_dict(5, trans_dim=C13, embed_dim=64, enc_dim=512, depth=1)
+    pre = 'point_encoder.visual.blocks.0.attn.'
+    lin = lambda name, bias: _linear_from(sd13[pre + name + '.weight'], sd13.get(pre + name + '.bias') if bias else None)
+    module = types.SimpleNamespace(q_proj=lin('q_proj', True), k_proj=lin('k_proj', False), v_proj=lin('v_proj', True), num_heads=H13)
+    g13 = torch.Generator().manual_seed(41)
+    x13 = torch.randn(B13, G13 + 1, C13, generator=g13)
+    with torch.no_grad():
+        hook(module, (x13,), None)
+    amap = ext.attention_maps['layer_0']
+    np.savez_compressed(os.path.join(OUT, 'g13_eva_attention_map.npz'), x=x13.numpy(), weights_seed=np.int64(5), heads=np.int64(H13),
+                        attn=amap.numpy())
+    print('g13 attention map', tuple(amap.shape), 'row sums', float(amap.sum(-1).min()), float(amap.sum(-1).max()))
+
+
+def _linear_from(w, b):
+    m = nn.Linear(w.shape[1], w.shape[0], bias=b is not None)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        if b is not None:
+            m.bias.copy_(b)
+    return m
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) >= 4 and sys.argv[1] == '--long-variant':
         return long_stream_variant(sys.argv[2], sys.argv[3])
     if '--only-long' in sys.argv:
         return long_streams()
+    if '--only-extras' in sys.argv:
+        return extras()
     torch.manual_seed(0)
     torch.set_num_threads(1)            # fixes CPU reduction order for reproducible fixtures
     dota_mixture, ua_ns, loop_code, fusion_code, banks = _reference_pieces()
@@ -553,6 +641,7 @@ def main():
                         threshold=np.float64(0.5), lambda_reg=np.float64(0.11), finals=torch.cat(fin11).numpy(), cache_logits=torch.cat(z211).numpy(),
                         final_keys=keys11.numpy(), final_counts=np.array([it[3] for c in sorted(cache11) for it in cache11[c]], dtype=np.int64))
     print('g11 cluster cache', keys11.shape)
+    extras()
     if '--skip-long' not in sys.argv:
         long_streams()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

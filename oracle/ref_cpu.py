@@ -358,6 +358,30 @@ def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
+def eva_attention_map(h: torch.Tensor, sd: Dict[str, torch.Tensor], pre: str, n_heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(hd)) of an EVA-style attention module on its input h (B,T,C) - the same q / k arithmetic as in
+    eva_block below; pinned by tests/golden/g13 (the reference's own hook arithmetic, extract_attention.py:115-160).  (B,H,T,T)."""
+    has = lambda k: (pre + k) in sd
+    p = lambda k: sd[pre + k]
+    B, T, C = h.shape
+    hd = C // n_heads
+    if has('attn.q_proj.weight'):
+        q = h @ p('attn.q_proj.weight').t()
+        k = h @ p('attn.k_proj.weight').t()
+        if has('attn.q_proj.bias'): q = q + p('attn.q_proj.bias')
+        if has('attn.k_proj.bias'): k = k + p('attn.k_proj.bias')
+        if has('attn.q_bias'): q = q + p('attn.q_bias')
+    else:
+        qkv = h @ p('attn.qkv.weight').t()
+        if has('attn.qkv.bias'):
+            qkv = qkv + p('attn.qkv.bias')
+        q, k, _ = qkv.split(C, dim=-1)
+        if has('attn.q_bias'): q = q + p('attn.q_bias')
+    q = q.reshape(B, T, n_heads, hd).transpose(1, 2)
+    k = k.reshape(B, T, n_heads, hd).transpose(1, 2)
+    return torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+
+
 def eva_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], pre: str, n_heads: int,
               ln_eps: float = 1e-6) -> torch.Tensor:
     """timm EvaBlock as instantiated by eva02_large_patch14_448 and called WITHOUT rope
@@ -389,7 +413,7 @@ def eva_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], pre: str, n_heads: i
     q = q.reshape(B, T, n_heads, hd).transpose(1, 2)
     k = k.reshape(B, T, n_heads, hd).transpose(1, 2)
     v = v.reshape(B, T, n_heads, hd).transpose(1, 2)
-    a = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1) @ v
+    a = eva_attention_map(h, sd, pre, n_heads) @ v                                        # (same q, k as formed above)
     a = a.transpose(1, 2).reshape(B, T, C)
     if has('attn.norm.weight'):
         a = _ln(a, p('attn.norm.weight'), p('attn.norm.bias'), ln_eps)
@@ -681,8 +705,9 @@ class DotaFull:
     fp16 scoring.  `dtype` = torch.float32 follows the reference arithmetic (incl. its .half() casts);
     torch.float64 keeps everything in double (no half casts) as the truth for error budgets."""
 
-    def __init__(self, cfg, input_shape, num_classes, clip_weights, dtype=torch.float32):
+    def __init__(self, cfg, input_shape, num_classes, clip_weights, dtype=torch.float32, streaming_update_Sigma=True):
         self.D, self.K, self.eps, self.dtype = input_shape, num_classes, cfg['epsilon'], dtype
+        self.streaming_update_Sigma = streaming_update_Sigma                              # :25, :54
         self.mu = clip_weights.T.to(dtype).clone()                                        # :27
         self.c = torch.ones(num_classes, dtype=dtype)                                     # :28
         self.Sigma = (cfg['sigma'] * torch.eye(input_shape, dtype=dtype)).repeat(num_classes, 1, 1)   # :29
@@ -698,9 +723,10 @@ class DotaFull:
         wx = y.T @ x
         new_mu = (wx + self.c[:, None] * self.mu) / (sw[:, None] + self.c[:, None])
         new_c = self.c + sw
-        d = x[:, None, :] - self.mu[None]                                                 # uses the OLD mean (:56)
-        delta = torch.einsum('bji,bjk->jik', y[:, :, None] * d, d)
-        self.Sigma = (self.c[:, None, None] * self.Sigma + delta) / (self.c[:, None, None] + sw[:, None, None])
+        if self.streaming_update_Sigma:                                                   # :54
+            d = x[:, None, :] - self.mu[None]                                             # uses the OLD mean (:56)
+            delta = torch.einsum('bji,bjk->jik', y[:, :, None] * d, d)
+            self.Sigma = (self.c[:, None, None] * self.Sigma + delta) / (self.c[:, None, None] + sw[:, None, None])
         self.overall_Sigma = self.Sigma.mean(0)
         self.mu, self.c = new_mu, new_c
 
@@ -751,12 +777,24 @@ def refine_values(cache_keys, all_probs, threshold, lambda_reg):
     return x / x.sum(1).unsqueeze(1), L_reg, it
 
 
+def refine_values_exact(cache_keys, all_probs, threshold, lambda_reg):
+    """utils/math_utils.py:97-111 (`online_value_refinement_old`: explicit inverse of the regularised Laplacian)."""
+    nk = F.normalize(cache_keys, p=2, dim=1)
+    W = nk @ nk.T
+    W[W < threshold] = 0
+    dis = torch.diag(1.0 / (torch.sqrt(W.sum(dim=1)) + 1e-8))
+    L_reg = (torch.eye(W.size(0), dtype=W.dtype) - dis @ W @ dis) + 2 * lambda_reg * torch.eye(W.size(0), dtype=W.dtype)
+    x = torch.linalg.inv(L_reg) @ (2 * lambda_reg * all_probs)
+    return x / x.sum(1).unsqueeze(1), L_reg
+
+
 class ClusterCache:
     """The single cluster cache of the original Uni-Adapter (Uni_Adapter.py:78-118,120-156,541-574): per predicted class up to
     `shot_capacity` prototypes [feature, confidence, prob, count]; a full class merges the new sample into its most similar
     prototype (confidence-weighted).  `step` = one pass of the loop body of the `not use_dota and not use_mode_dota` branch."""
 
-    def __init__(self, text_kd, shot_capacity=30, beta=150.0, threshold=0.5, lambda_reg=0.11, dtype=torch.float32):
+    def __init__(self, text_kd, shot_capacity=30, beta=150.0, threshold=0.5, lambda_reg=0.11, dtype=torch.float32, exact_inverse=False):
+        self.exact_inverse = exact_inverse                 # args.use_new_approximation False: compute_cache_logits_old (:159-189)
         self.text = text_kd.to(dtype)                      # (K,D); the reference carries clip_weights = text^T (D,K), contiguous
         self.cw = self.text.T.contiguous()
         self.cap, self.beta, self.thr, self.lam, self.dtype = shot_capacity, beta, threshold, lambda_reg, dtype
@@ -787,7 +825,10 @@ class ClusterCache:
     def cache_logits(self, f):                                           # compute_cache_logits :120-156
         keys = torch.cat([it[0] for c in sorted(self.cache) for it in self.cache[c]], 0)
         probs = torch.cat([it[2] for c in sorted(self.cache) for it in self.cache[c]], 0)
-        new, _, self.last_cg_iterations = refine_values(keys, probs, self.thr, self.lam)
+        if self.exact_inverse:
+            new, _ = refine_values_exact(keys, probs, self.thr, self.lam)
+        else:
+            new, _, self.last_cg_iterations = refine_values(keys, probs, self.thr, self.lam)
         cls = new.argmax(1)
         vals = F.one_hot(cls, num_classes=self.text.shape[0]).to(self.dtype)
         vals = vals / (vals.sum(0) + 1e-6)

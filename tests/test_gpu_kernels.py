@@ -1056,8 +1056,74 @@ def test_cluster_cache_stream_vs_reference_fixture(ua, golden_dir):
     idx = c._idx.cpu()
     assert (c.keys.cpu()[idx] - _t(g['final_keys'])).abs().max().item() < 1e-6
     assert c.count.cpu()[idx].tolist() == g['final_counts'].tolist()
-    with pytest.raises(NotImplementedError):
-        ClusterCache(text, dict(hp, use_new_approximation=False))
+
+
+def test_cluster_cache_exact_inverse_vs_reference_fixture(ua, golden_dir):
+    """use_new_approximation=False: compute_cache_logits_old / online_value_refinement_old (Uni_Adapter.py:159-189,
+    utils/math_utils.py:97-111) - the regularised Laplacian inverted by the blocked SPD inverse - on the stream of g11b."""
+    from uni_adapter_amd.uni_cache import ClusterCache
+    g = _load(golden_dir, 'g11b_cluster_cache_exact_inverse.npz')
+    text, feats = _t(g['text']), _t(g['feats'])
+    hp = {'shot_capacity': int(g['cap']), 'beta': float(g['beta']), 'threshold': float(g['threshold']), 'lambda_reg': float(g['lambda_reg']),
+          'use_new_approximation': False}
+    c = ClusterCache(text, hp)
+    fin, z2 = [], []
+    for i in range(feats.shape[0]):
+        f, z = c.step(feats[i:i + 1])
+        fin.append(f.cpu()); z2.append(z.cpu())
+    fin, z2 = torch.cat(fin), torch.cat(z2)
+    rf, rz = _t(g['finals']), _t(g['cache_logits'])
+    assert (z2 - rz).abs().max().item() <= 2e-6 * max(1.0, rz.abs().max().item())
+    assert (fin - rf).abs().max().item() <= 1e-5 * rf.abs().max().item()
+    assert torch.equal(fin.argmax(1), rf.argmax(1))
+
+
+def test_dota_mean_only_vs_reference_fixture(ua, golden_dir):
+    """DOTA(streaming_update_Sigma=False) (dota.py:54): only means and counts move; g10b = the reference class's outputs."""
+    from uni_adapter_amd.dota import DOTA
+    g = _load(golden_dir, 'g10b_dota_mean_only.npz')
+    text, X, Y = _t(g['text']), _t(g['X']), _t(g['Y'])
+    K, D = text.shape
+    m = DOTA({'epsilon': float(g['eps']), 'sigma': float(g['sigma'])}, D, K, text.T.clone(), streaming_update_Sigma=False)
+    sc = []
+    for i in range(X.shape[0]):
+        sc.append(m.predict(X[i:i + 1].half()).float().cpu())
+        m.fit(X[i:i + 1], Y[i:i + 1]); m.update()
+    assert (m.mu.cpu() - _t(g['mu'])).abs().max().item() < 1e-6
+    assert (m.c.cpu() - _t(g['c'])).abs().max().item() < 1e-6
+    assert torch.equal(m.Sigma[0].cpu(), _t(g['Sigma0']))
+    Lr, Lm = _t(g['Lambda']), m.Lambda.float().cpu()
+    assert (Lm - Lr).abs().max().item() <= 2.0 ** -10 * Lr.abs().max().item()                    # one fp16 step of the large entries
+    S, Sr = torch.cat(sc), _t(g['scores'])
+    step = 2.0 ** (torch.floor(torch.log2(Sr.abs().max())).item() - 10)
+    assert (S - Sr).abs().max().item() <= step and torch.equal(S.argmax(1), Sr.argmax(1))
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_attention_kernels_vs_the_references_attention_maps(ua, golden_dir, split):
+    """g13: attention maps produced by the reference's own hook arithmetic for EVA-style modules (extract_attention.py:115-160)
+    on seeded weights.  The HIP attention kernels compute softmax(q k^T / sqrt(hd)) v: fed with the same q, k and with v from
+    v_proj, their output must equal (reference map) @ v."""
+    g = _load(golden_dir, 'g13_eva_attention_map.npz')
+    x, amap = _t(g['x']), _t(g['attn']).double()
+    B, T, C = x.shape; H = int(g['heads']); hd = C // H; G = T - 1
+    sd = O.make_uni3d_state_dict(int(g['weights_seed']), trans_dim=C, embed_dim=64, enc_dim=512, depth=1)
+    pre = 'point_encoder.visual.blocks.0.attn.'
+    q = x @ sd[pre + 'q_proj.weight'].t() + sd[pre + 'q_proj.bias']
+    k = x @ sd[pre + 'k_proj.weight'].t()
+    v = x @ sd[pre + 'v_proj.weight'].t() + sd[pre + 'v_proj.bias']
+    want = (amap @ v.reshape(B, T, H, hd).transpose(1, 2).double()).transpose(1, 2).reshape(B, T, C)      # (B,T,C)
+    # HIP row layout: patch token g of cloud b at b*G+g, the CLS token (reference position 0) of cloud b at B*G+b
+    order = torch.cat([torch.arange(1, T) + b * T for b in range(B)] + [torch.tensor([b * T]) for b in range(B)])
+    qkv = torch.cat([q, k, v], -1).reshape(B * T, 3 * C)[order].contiguous()
+    out = torch.zeros(B * T, C, device='cuda')
+    if not split:
+        ua.call('ua_attention', ua.ptr(dev(qkv)), 3 * C, ua.ptr(out), C, B, G, H, hd, ua.stream_ptr())
+    else:
+        qs = _split(ua, dev(qkv), 3 * C, 1.0)
+        ua.call('ua_attention_split', qs.data_ptr(), 3 * C, 1.0, ua.ptr(out), C, None, 0, 1.0, B, G, H, hd, ua.stream_ptr())
+    got = out.cpu().double()
+    assert (got - want.reshape(B * T, C)[order]).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize('N', [2048, 2304, 3328, 5504])

@@ -276,3 +276,35 @@ def test_g12_reference_runs_spread(golden_dir):
             diam = np.maximum(diam, np.abs(T[u] - T[v]).max(1))
             assert 0.7 < float((g['pred_' + u] == g['pred_' + v]).mean()) < 0.95
     assert (diam[:3] < 1e-3).all() and diam[5] > 1.0 and np.median(diam[64:]) > 10.0
+
+
+def test_g10b_dota_mean_only_is_bit_exact(golden_dir):
+    """dota.DOTA(streaming_update_Sigma=False) (dota.py:54): covariances stay sigma*I, means / counts / Lambda as the reference."""
+    g = _load(golden_dir, 'g10b_dota_mean_only.npz')
+    text, X, Y = _t(g['text']), _t(g['X']), _t(g['Y'])
+    d = O.DotaFull({'epsilon': float(g['eps']), 'sigma': float(g['sigma'])}, text.shape[1], text.shape[0], text.T.clone(), streaming_update_Sigma=False)
+    for i in range(X.shape[0]):
+        assert np.array_equal(d.predict(X[i:i + 1].half()).float().numpy()[0], g['scores'][i])
+        d.fit(X[i:i + 1], Y[i:i + 1]); d.update()
+    assert np.array_equal(d.mu.numpy(), g['mu']) and np.array_equal(d.c.numpy(), g['c'])
+    assert np.array_equal(d.Sigma[0].numpy(), g['Sigma0']) and np.array_equal(d.Lambda.float().numpy(), g['Lambda'])
+
+
+def test_g11b_cluster_cache_exact_inverse_is_bit_exact(golden_dir):
+    """compute_cache_logits_old (Uni_Adapter.py:159-189, math_utils.online_value_refinement_old) over the 40-sample stream."""
+    g = _load(golden_dir, 'g11b_cluster_cache_exact_inverse.npz')
+    c = O.ClusterCache(_t(g['text']), int(g['cap']), float(g['beta']), float(g['threshold']), float(g['lambda_reg']), exact_inverse=True)
+    for i in range(g['feats'].shape[0]):
+        final, z2 = c.step(_t(g['feats'][i:i + 1]))
+        assert np.array_equal(z2.numpy()[0], g['cache_logits'][i]), i
+        assert np.array_equal(final.numpy()[0], g['finals'][i]), i
+
+
+def test_g13_eva_attention_map_matches_the_references_hook_arithmetic(golden_dir):
+    """The q / k / scale / softmax part of the EVA block restatement against attention maps produced by the reference's own
+    hook for EVA-style modules (extract_attention.py:115-160) on seeded weights."""
+    g = _load(golden_dir, 'g13_eva_attention_map.npz')
+    sd = O.make_uni3d_state_dict(int(g['weights_seed']), trans_dim=g['x'].shape[2], embed_dim=64, enc_dim=512, depth=1)
+    a = O.eva_attention_map(_t(g['x']), sd, 'point_encoder.visual.blocks.0.', int(g['heads']))
+    assert a.shape == g['attn'].shape
+    assert np.array_equal(a.numpy(), g['attn'])

@@ -145,14 +145,18 @@ to_half_kernel(const float* __restrict__ x, __half* __restrict__ y, size_t n) {
 
 extern "C" int ua_dota_fit(float* Sigma, float* mu, float* c, const float* x, const float* y,
                            int32_t B, int32_t K, int32_t D, float eps, float* overall_Sigma, float* A, void* stream) {
-    UA_CHECK_PTR(Sigma); UA_CHECK_PTR(mu); UA_CHECK_PTR(c); UA_CHECK_PTR(x); UA_CHECK_PTR(y); UA_CHECK_PTR(overall_Sigma); UA_CHECK_PTR(A);
-    UA_CHECK_ALIGN16(Sigma); UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(x); UA_CHECK_ALIGN16(overall_Sigma); UA_CHECK_ALIGN16(A);
+    UA_CHECK_PTR(mu); UA_CHECK_PTR(c); UA_CHECK_PTR(x); UA_CHECK_PTR(y);
+    UA_CHECK_ALIGN16(mu); UA_CHECK_ALIGN16(x);
     if (B <= 0 || K <= 0 || D <= 0) return UA_EINVAL;
     if (D % 4 != 0 || B > 64) return UA_EUNSUPPORTED;
     hipStream_t st = ua::as_stream(stream);
-    hipLaunchKernelGGL(dota_fit_kernel, dim3((D / 4 + 63) / 64, D), dim3(64), 0, st, Sigma, mu, c, x, y, B, K, D,
-                       (float)(1.0 - (double)eps), eps, overall_Sigma, A);
-    UA_LAUNCH_CHECK();
+    if (Sigma) {      // Sigma == NULL: streaming_update_Sigma = False (dota.py:54) - covariances, their mean and A stay as they are
+        UA_CHECK_PTR(overall_Sigma); UA_CHECK_PTR(A);
+        UA_CHECK_ALIGN16(Sigma); UA_CHECK_ALIGN16(overall_Sigma); UA_CHECK_ALIGN16(A);
+        hipLaunchKernelGGL(dota_fit_kernel, dim3((D / 4 + 63) / 64, D), dim3(64), 0, st, Sigma, mu, c, x, y, B, K, D,
+                           (float)(1.0 - (double)eps), eps, overall_Sigma, A);
+        UA_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(dota_mean_kernel, dim3(K), dim3(256), 0, st, mu, c, x, y, B, K, D);
     UA_LAUNCH_CHECK();
     return UA_OK;

@@ -23,8 +23,7 @@ class DOTA(torch.nn.Module):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('uni_adapter_amd.DOTA needs a HIP device (MI355X); no CPU path')
-        if not streaming_update_Sigma:
-            raise NotImplementedError('streaming_update_Sigma=False (mean-only updates) is not built')
+        self.streaming_update_Sigma = bool(streaming_update_Sigma)       # False: means / counts only, Sigma stays sigma * I (dota.py:54)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         D, K = int(input_shape), int(num_classes)
         if D % 64 != 0:
@@ -58,9 +57,10 @@ class DOTA(torch.nn.Module):
         if self.update_prior:
             self.cum_soft_labels = self.cum_soft_labels + y
             self.prior_step += 1
-        lib.call('ua_dota_fit', lib.ptr(self.Sigma), lib.ptr(self.mu), lib.ptr(self.c), lib.ptr(x), lib.ptr(y), x.shape[0],
-                 self.num_classes, self.input_shape, float(self.epsilon), lib.ptr(self.overall_Sigma), lib.ptr(self._A), lib.stream_ptr())
-        self._dirty = True
+        lib.call('ua_dota_fit', lib.ptr(self.Sigma) if self.streaming_update_Sigma else None, lib.ptr(self.mu), lib.ptr(self.c), lib.ptr(x),
+                 lib.ptr(y), x.shape[0], self.num_classes, self.input_shape, float(self.epsilon), lib.ptr(self.overall_Sigma), lib.ptr(self._A),
+                 lib.stream_ptr())
+        self._dirty = self.streaming_update_Sigma
 
     # -- dota.py:69-72 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -83,6 +83,8 @@ class DOTA(torch.nn.Module):
     def _gemm(self, A, W, C, M, N, K, neg=False, residual=None):
         e = lib.GemmEpilogue()
         if neg:
+            if self._neg.numel() < N:
+                self._neg = torch.full((N,), -1.0, device=self._neg.device)
             e.scale = self._neg.data_ptr()
         if residual is not None:
             e.residual = residual.data_ptr(); e.ldr = residual.stride(0)
@@ -132,3 +134,32 @@ class DOTA(torch.nn.Module):
         """final = clip + w * dota with w = clamp(rho * mean(c) / batch, max=eta)  (usage note dota_mixture.py:288-293)."""
         w = torch.clamp(rho * self.c.mean() / batch, max=eta)
         return clip_logits + w * dota_logits.float()
+
+
+class SpdInverse:
+    """Inverse of a symmetric positive-definite matrix of any size on the device: zero-pads to a multiple of 64 with an
+    identity block, runs DOTA's blocked Schur-complement inversion (64 x 64 leaves in LDS, everything else `ua_gemm`) and
+    `refine_steps` Newton-Schulz steps.  Used by the exact-inverse refinement of the cluster cache (utils/math_utils.py:97-111)."""
+
+    def __init__(self, device, refine_steps=2):
+        self.dev, self.refine_steps = device, refine_steps
+        self._neg = torch.full((64,), -1.0, device=device)
+
+    _gemm = DOTA._gemm
+    _invert = DOTA._invert
+
+    @torch.no_grad()
+    def __call__(self, A):
+        n = A.shape[0]
+        N = (n + 63) // 64 * 64
+        Ap = torch.eye(N, device=self.dev)
+        Ap[:n, :n] = A
+        X = torch.empty(N, N, device=self.dev)
+        self._invert(Ap, X)
+        U, X2 = torch.empty(N, N, device=self.dev), torch.empty(N, N, device=self.dev)
+        for _ in range(self.refine_steps):
+            X.copy_(0.5 * (X + X.t()))
+            torch.mul(X, 2.0, out=X2)
+            self._gemm(X, Ap, U, N, N, N)
+            self._gemm(X, U, X, N, N, N, neg=True, residual=X2)
+        return X[:n, :n]
