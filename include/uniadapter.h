@@ -222,7 +222,8 @@ int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t rows
 
 /* C = A @ W^T with the accuracy of an fp32 GEMM on the f16 matrix cores: both operands are
  * H32L32 pairs and the product is evaluated as hi*hi + hi*lo + lo*hi (three
- * v_mfma_f32_32x32x16_f16 per block, fp32 accumulate; the dropped lo*lo term is 2^-22 relative).
+ * v_mfma_f32_16x16x32_f16 per block by default - UA_SPLIT_SCHEDULE=8 selects the 32x32x16 form -, fp32 accumulate; the dropped
+ * lo*lo term is 2^-22 relative).
  * gfx950 has no TF32/xf32 path and its f32 MFMA runs at 1/16 of the f16 rate, so this is 16/3 x
  * the f32-MFMA roofline at the same numerical quality (measured: tests/test_gpu_kernels.py).
  * A: (M, K) split, scale a_scale; W: (N, K) split, scale w_scale; accumulators are multiplied by

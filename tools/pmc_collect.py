@@ -5,7 +5,8 @@ streaming reads (MI355X_MICROARCH.md, HBM section): fetch_bytes_corrected = FETC
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-KEEP = ('gemm_split_kernel', 'gemm_f32_mfma_kernel', 'attention_split_kernel', 'gmm_loglik_kernel', 'gmm_step1_kernel', 'gmm_step_kernel', 'layernorm_kernel')
+KEEP = ('gemm_split_kernel', 'gemm_f32_mfma_kernel', 'attention_split_kernel', 'gmm_loglik_kernel', 'gmm_step1_kernel', 'gmm_step_kernel', 'layernorm_kernel',
+        'gmm_operand_kernel', 'gmm_query_operand_kernel')
 acc = defaultdict(lambda: defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):

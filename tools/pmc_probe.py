@@ -15,6 +15,23 @@ import uni_adapter_amd  # noqa: E402,F401
 from uni_adapter_amd import lib  # noqa: E402
 from uni_adapter_amd.lib import GemmEpilogue  # noqa: E402
 
+PART = os.environ.get('UA_PMC_PART', 'main')
+if PART == 'sim':
+    # batched-query MFMA similarity at BASELINE configs[4] size: operand build, 512 queries in split and plain-f16 form
+    from uni_adapter_amd.dota_mixture import DOTA_mix
+    from uni_adapter_amd import synthetic
+    K, M, D, B = 4096, 16, 1024, 512
+    text = synthetic.text_bank(K, D, 1)
+    mdl = DOTA_mix({'epsilon': 1e-4, 'sigma': 1e-4}, D, K, text.t(), num_modes=M)
+    xq = torch.nn.functional.normalize(torch.randn(B, D, device='cuda'), dim=1)
+    for _ in range(3):
+        mdl.mfma_prepare(B)
+    for prec in ('split', 'f16'):
+        for _ in range(3):
+            mdl.predict_mfma(xq, precision=prec, reuse_operand=True)
+    torch.cuda.synchronize()
+    print('pmc probe (sim) done: operand bytes read+written', 16 * K * M * D, 'GEMM flops (algorithmic)', 4 * B * K * M * D)
+    raise SystemExit
 K, M, D = 4096, 16, 1024
 mu = torch.randn(K, M, D, device='cuda') * 0.03
 var = 1e-4 * (1 + torch.rand(K, M, D, device='cuda'))

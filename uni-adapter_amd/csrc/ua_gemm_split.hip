@@ -38,6 +38,7 @@ struct SplitArgs {
     int tiles_n, n_tiles;
     int stagger;                                     // waves 4-7 run half a slab behind waves 0-3
     int block_order;                                 // 2D-blocked tile walk (L2 locality)
+    int br, bc;                                      // its block: br row panels x bc column tiles
 #ifdef UA_SPLIT_TRACE
     unsigned long long* trace;                       // [block][wave][6] cycle accumulators (tools/gemm_trace.py)
     unsigned long long* timeline;                    // [block][8] s_memrealtime (100 MHz): start, main loop end, block end, full?, 4 epilogue stamps (wave 0)
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     if (g.block_order && g.tiles_n >= 8 && tile < n_full) {          // (narrow outputs are already compact; measured: no gain below 8 column tiles)
         // 2D-blocked walk of the full tiles: the ~32 workgroups an XCD runs at a time cover 4 row panels x 8 column
         // tiles (12 operand panels per K-tile step in its L2) instead of 1-3 row panels x all column tiles (up to 24)
-        constexpr int BR = 4, BC = 8;
+        const int BR = g.br, BC = g.bc;
         const int rows_full = g.M / SBM;
         const int rb = tile / (BR * g.tiles_n);
         const int h = min(BR, rows_full - rb * BR);                         // row panels in this row block
@@ -554,6 +555,9 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
     const int sched = g_sched;
     if (g_block_order < 0) { const char* e = getenv("UA_SPLIT_TILE_ORDER"); g_block_order = e ? atoi(e) : 1; }
     g.block_order = g_block_order;
+    static const int env_br = [] { const char* e = getenv("UA_SPLIT_BR"); return e ? atoi(e) : 4; }();
+    static const int env_bc = [] { const char* e = getenv("UA_SPLIT_BC"); return e ? atoi(e) : 8; }();
+    g.br = env_br; g.bc = env_bc;
     g.stagger = stagger;
 #ifdef UA_SPLIT_TRACE
     g.trace = g_trace; g.timeline = g_timeline;
@@ -833,7 +837,7 @@ extern "C" int ua_gmm_loglik_mfma(const float* x, int32_t B, int32_t K, int32_t 
     if (fused && scores) { g.ep.act = 4; g.ep.lse = scores; g.ep.ld_lse = K; g.ep.lse_group = M; }
     const int tiles_m = (B + SBM - 1) / SBM, tiles_n = (KM + SBN - 1) / SBN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
-    g.block_order = 1; g.stagger = 1;
+    g.block_order = 1; g.stagger = 1; g.br = 4; g.bc = 8;
     const size_t lds = (size_t)S_LDS;
     static bool attr_set = false;
     if (!attr_set) {
