@@ -10,20 +10,24 @@ Pinning status (see DESIGN.md "Oracle"):
     reference `dota_mixture.DOTA_mix` (tests/golden/g1_*, g2_*; oracle/make_golden.py)
   * clip logits / entropy / fusion / alignment loss (A7, A12, A13) - pinned vs functions extracted
     from the reference `Uni_Adapter.py` (g2_*, g3_*, g4_*)
+  * the whole loop body incl. residual learning (A13, A14) - pinned BIT FOR BIT: every step of the g2 streams and of the
+    256-step g12 stream at the generator's thread count (run a: 1 thread, run b: 8 threads), and run e (the reference in
+    fp64) to 1e-9 over all 256 steps (tests/test_oracle_golden.py::test_g12_*)
   * square_distance / knn_point / Group / Encoder (A2-A4)     - pinned vs `models/point_encoder.py`
     definitions executed with FPS supplied explicitly (g5_*, g6_*)
   * farthest point sampling (A1)  - pinned only for the pure-torch flavour
     (`models/ulip/pointbert/misc.py:40-60`, g7_*); the pointnet2_ops CUDA flavour
     (start index 0, skip |p|^2<=1e-3) is third-party and absent: PARITY UNPINNED
-  * timm EVA02 blocks (A6) - third-party, absent: PARITY UNPINNED; restated from the structure
-    recorded in SURVEY.md row A6 / `extract_attention.py:121-177`
+  * timm EVA02 blocks (A6) - third-party, absent: PARITY UNPINNED except the q / k / scale / softmax part, which is pinned
+    bit-exact by attention maps from the reference's own hook arithmetic (`extract_attention.py:115-160`, g13_*); the rest is
+    restated from the structure recorded in SURVEY.md row A6
   * ULIP-2 PointBERT encoder (A4b) - pinned vs the reference `PointTransformer` + dvae `Group`/`Encoder` run with the
     FPS result supplied (g8_*)
   * OpenShape PPAT (F1) - set-abstraction layer and transformer blocks pinned vs `pointnet_util.PointNetSetAbstraction`
     and `ppta.Transformer` (g9_*); the three glue lines that need torch_redstone (absent) are PARITY UNPINNED
-  * full-covariance DOTA (F2) - pinned, bit-exact vs the reference `dota.DOTA` class (g10_*)
+  * full-covariance DOTA (F2) - pinned, bit-exact vs the reference `dota.DOTA` class (g10_*; g10b_*: streaming_update_Sigma=False)
   * original cluster cache + graph refinement (F3) - pinned, bit-exact vs `update_cache` / `compute_cache_logits` /
-    `utils/math_utils.py` (g11_*)
+    `compute_cache_logits_old` / `utils/math_utils.py` (g11_*, g11b_*)
 
 All functions take/return torch CPU tensors; `dtype` selects fp32 (reference arithmetic) or
 fp64 (used by tests as the "true value" to bound fp32 noise).
