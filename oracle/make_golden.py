@@ -256,10 +256,13 @@ def _reference_pieces():
 #   e: in fp64 (see run_stream) - the "truth" the fp32 runs scatter around
 # and per-step final logits / predictions of each are stored.  Tests assert the HIP path against the envelope of a-d.
 LONG = dict(bank='modelnet40', M=8, n=256, seed=14)
+LONG_STREAMS = {'modelnet40': dict(bank='modelnet40', M=8, n=256, seed=14),          # g12_long_stream_modelnet40.npz
+                'scanobjectnn': dict(bank='scanobjectnn', M=8, n=256, seed=15)}      # g12_long_stream_scanobjectnn.npz
 LONG_VARIANTS = ('a', 'b', 'c', 'd', 'e')
 
 
-def long_stream_variant(variant, out_path):
+def long_stream_variant(variant, out_path, stream='modelnet40'):
+    LONG.update(LONG_STREAMS[stream])
     dota_mixture, ua_ns, loop_code, _, banks = _reference_pieces()
     text = banks[LONG['bank']]
     K, D = text.shape
@@ -292,12 +295,13 @@ def long_stream_variant(variant, out_path):
     np.savez_compressed(out_path, final=final, pred=pred.astype(np.int64), dota_raw=dz, clip=clip, w=out['w'], loss=out['loss'])
 
 
-def long_streams():
+def long_streams(stream='modelnet40'):
     """Runs the five variants as parallel child processes (several minutes each) and merges them into one fixture."""
     import subprocess
     import tempfile
+    LONG.update(LONG_STREAMS[stream])
     tmp = tempfile.mkdtemp(prefix='ua_g12_')
-    procs = {v: subprocess.Popen([sys.executable, os.path.abspath(__file__), '--long-variant', v, os.path.join(tmp, v + '.npz')])
+    procs = {v: subprocess.Popen([sys.executable, os.path.abspath(__file__), '--long-variant', v, os.path.join(tmp, v + '.npz'), stream])
              for v in LONG_VARIANTS}
     for v, pr in procs.items():
         if pr.wait() != 0:
@@ -317,7 +321,7 @@ def long_streams():
             out['loss_' + v] = d['loss']
         if v == 'a':
             out['w'] = d['w']
-    np.savez_compressed(os.path.join(OUT, 'g12_long_stream_modelnet40.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, f'g12_long_stream_{stream}.npz'), **out)
     fa_, fe = out['final_a'].astype(np.float64), out['final_e']
     for v in LONG_VARIANTS[1:]:
         dv = np.abs(out['final_' + v].astype(np.float64) - fa_).max(1)
@@ -414,9 +418,12 @@ def _linear_from(w, b):
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) >= 4 and sys.argv[1] == '--long-variant':
-        return long_stream_variant(sys.argv[2], sys.argv[3])
+        return long_stream_variant(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 'modelnet40')
     if '--only-long' in sys.argv:
-        return long_streams()
+        for st in LONG_STREAMS:
+            if '--long-stream' not in sys.argv or sys.argv[sys.argv.index('--long-stream') + 1] == st:
+                long_streams(st)
+        return
     if '--only-extras' in sys.argv:
         return extras()
     torch.manual_seed(0)
@@ -643,7 +650,8 @@ def main():
     print('g11 cluster cache', keys11.shape)
     extras()
     if '--skip-long' not in sys.argv:
-        long_streams()
+        for st in LONG_STREAMS:
+            long_streams(st)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden bytes', tot)
 

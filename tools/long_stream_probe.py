@@ -1,7 +1,8 @@
-"""Scratch: HIP engine on the golden residual-learning streams, printed against the reference variants."""
+"""HIP engine on the golden residual-learning streams, printed against the reference runs of g12 (what the calibrated
+assertions of tests/test_gpu_harness.py::test_long_stream_against_the_references_own_spread are built from).  Run on the GPU box."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import uni_adapter_amd  # noqa
 from uni_adapter_amd.Uni_Adapter import TtaEngine

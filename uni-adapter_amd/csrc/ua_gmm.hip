@@ -302,16 +302,29 @@ __global__ void __launch_bounds__(1024) gmm_step_kernel(StepArgs a) {
 // budget of a 1024-thread workgroup.  Same expressions in the same order as gmm_step_kernel: bit-identical state
 // and scores (tests/test_gpu_kernels.py::test_stream_step_kernel_is_bit_identical_to_the_generic_one).
 // ------------------------------------------------------------------------------------------
+// logsumexp over the first M lanes' values (lane i holds value i; lanes >= M are ignored): same association as lse_modes
+__device__ __forceinline__ float lse_lanes(float v, int M, int lane) {
+    v = lane < M ? v : -INFINITY;
+    const float mx = ua::wave_max(v);
+    const float e = lane < M ? expf(v - mx) : 0.f;
+    float s = 0.f;
+    for (int i = 0; i < M; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), i));
+    return mx + logf(s);
+}
+
+// Exchanges per class (one LDS slot each, one barrier between a slot's write and its reads):
+//   A: query joint + first-fit joint of every mode (both use the old pi)   -> barrier A -> scores, responsibilities of fit 1
+//   B: count after fit 1 + second-fit log-likelihood (does not depend on pi) -> barrier B -> every wave forms sum_m c, the
+//      new pi_i and joint_i of ALL modes on its lanes (one division and one logf per lane, in parallel), its logsumexp,
+//      and fit 2;  the count after fit 2 is exchanged at barrier A of the NEXT class (the final pi of a class is only
+//      stored, nobody waits for it) - unless the per-sample constants of the residual loop are emitted, which need it at once.
+// Two barriers per class instead of five; expressions and summation orders are those of gmm_step_kernel (bit-identical).
 template <int VEC>
 __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     constexpr int D = 256 * VEC;
     __shared__ __attribute__((aligned(16))) float s_x[3][D];     // query (fp16-rounded if asked), sample, augmented sample
-    // one LDS slot per exchange of a class (query scores, two E-steps, two count sums): a slot written in class k+1 was last
-    // read several barriers earlier, so only the barrier between a slot's write and its reads is needed (5 per class, not 10)
-    __shared__ float s_jq[kMaxModes];
-    __shared__ float s_jf[2][kMaxModes];
-    __shared__ float s_cf[2][kMaxModes];
-    const int m = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float s_jq[kMaxModes], s_j0[kMaxModes], s_c0[kMaxModes], s_l1[kMaxModes], s_c1[kMaxModes];
+    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int M = a.M, K = a.K;
     const float eps = a.eps;
     // Everything a class needs from global memory is requested one class ahead: the vector-memory counter retires in
@@ -334,6 +347,8 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     // loop body and - the counter being in-order, and the prefetch below conditional - also waits for the prefetch there
     __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
     __syncthreads();
+    const bool now = a.inv_var != nullptr;                                               // final pi needed inside the class body
+    bool have_prev = false;                                                              // (wave-uniform)
     for (; k < K; k += gridDim.x) {
         const int kn = k + gridDim.x;
         if (kn < K) {
@@ -343,26 +358,46 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
         const size_t off = ((size_t)k * M + m) * D;
         double ld, mh, mh1 = 0.0;
         row_logdet_maha<VEC, true>(r, s_x[0], s_x[1], eps, lane, ld, mh, mh1);        // log-det, query and first-fit distances
-        {   // predict on the state before any fit (dota_mixture.py:250-258)
-            const float ll = (float)(-0.5 * (ld + mh));
-            if (lane == 0) s_jq[m] = logf(pi_km + 1e-10f) + ll;
-            __syncthreads();
-            if (m == 0) {                                                               // wave-uniform
-                const float sc = lse_modes_wave(s_jq, M, lane);
-                if (lane == 0) a.scores[k] = sc;
+        {
+            const float logpi = logf(pi_km + 1e-10f);
+            if (lane == 0) {
+                s_jq[m] = logpi + (float)(-0.5 * (ld + mh));                            // predict (dota_mixture.py:250-258)
+                s_j0[m] = logpi + (float)(-0.5 * (ld + mh1));                           // E-step of fit 1 (:176-180)
             }
+        }
+        __syncthreads();                                                                // A
+        if (have_prev) {                                                                // final pi of the previous class (:229-230)
+            float Ck = 0.f;
+            for (int i = 0; i < M; ++i) Ck += s_c1[i];
+            if (lane == 0) a.pi[(k - (int)gridDim.x) * M + m] = s_c1[m] / (Ck + 1e-10f);
+        }
+        if (m == 0) {                                                                   // wave-uniform
+            const float sc = lse_modes_wave(s_jq, M, lane);
+            if (lane == 0) a.scores[k] = sc;
         }
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {                                                   // fits :162-234, B = 1
             const float* X = s_x[1 + f];
-            const float gk = f ? g1 : g0;
-            if (f > 0) { double unused; row_logdet_maha<VEC, false>(r, X, X, eps, lane, ld, mh1, unused); }   // var changed
-            const float logpi = logf(pi_km + 1e-10f);
-            float* s_j = s_jf[f];
-            if (lane == 0) s_j[m] = logpi + (float)(-0.5 * (ld + mh1));
-            __syncthreads();
-            const float lse = lse_modes_wave(s_j, M, lane);
-            const float g = gk * expf(s_j[m] - lse);                                   // :183-187
+            float g;
+            if (f == 0) {
+                const float lse = lse_modes_wave(s_j0, M, lane);
+                g = g0 * expf(s_j0[m] - lse);                                          // :183-187
+            } else {
+                // what this wave contributes to fit 2's E-step: its count and its log-likelihood under the updated row (var changed)
+                double unused;
+                row_logdet_maha<VEC, false>(r, X, X, eps, lane, ld, mh1, unused);
+                if (lane == 0) { s_c0[m] = c_km; s_l1[m] = (float)(-0.5 * (ld + mh1)); }
+                __syncthreads();                                                        // B
+                // pi of every mode after fit 1 (:229-230), joint of every mode on the lanes, responsibilities
+                float Ck = 0.f;
+                for (int i = 0; i < M; ++i) Ck += s_c0[i];
+                const float ci = lane < M ? s_c0[lane] : 0.f;
+                const float pii = ci / (Ck + 1e-10f);
+                const float ji = lane < M ? logf(pii + 1e-10f) + s_l1[lane] : -INFINITY;
+                const float lse = lse_lanes(ji, M, lane);
+                const float jm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ji), m));
+                g = g1 * expf(jm - lse);
+            }
             const float sum_gamma = g;                                                  // :190
             const float c_new = c_km + sum_gamma;                                       // :196
             const float den = c_new + 1e-10f;
@@ -384,17 +419,17 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             }
 #undef UA_UPD1
             c_km = c_new;
-            if (lane == 0) s_cf[f][m] = c_new;
-            __syncthreads();
-            float Ck = 0.f;
-            for (int i = 0; i < M; ++i) Ck += s_cf[f][i];
-            pi_km = c_km / (Ck + 1e-10f);                                               // :229-230
-            cc += gk;                                                                   // :233
+            cc += f ? g1 : g0;                                                          // :233
         }
         store_row<VEC>(r, a.mu, a.var, off, lane);
-        if (lane == 0) { a.c[k * M + m] = c_km; a.pi[k * M + m] = pi_km; }
+        if (lane == 0) { a.c[k * M + m] = c_km; s_c1[m] = c_km; }
         if (threadIdx.x == 0) a.class_counts[k] = cc;
-        if (a.inv_var) {                                   // gmm_prepare_kernel on the rows still in registers (same expressions)
+        if (now) {                                         // workgroup-uniform: pi at once, then gmm_prepare_kernel on the rows still in registers
+            __syncthreads();
+            float Ck = 0.f;
+            for (int i = 0; i < M; ++i) Ck += s_c1[i];
+            pi_km = c_km / (Ck + 1e-10f);
+            if (lane == 0) a.pi[k * M + m] = pi_km;
             float4* po = reinterpret_cast<float4*>(a.inv_var + off);
             double acc = 0.0;
 #pragma unroll
@@ -405,8 +440,17 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             }
             acc = wave_sum(acc);
             if (lane == 0) a.row_const[k * M + m] = (float)((double)logf(pi_km + 1e-10f) - 0.5 * acc);
+            __syncthreads();                               // s_c1 is rewritten by the next class
+        } else {
+            have_prev = true;
         }
         if (kn < K) { r = nx; c_km = c_nx; pi_km = pi_nx; g0 = g0_nx; g1 = g1_nx; cc = cc_nx; }
+    }
+    if (have_prev) {                                       // final pi of this workgroup's last class (k has run past it by one stride)
+        __syncthreads();
+        float Ck = 0.f;
+        for (int i = 0; i < M; ++i) Ck += s_c1[i];
+        if (lane == 0) a.pi[(k - (int)gridDim.x) * M + m] = s_c1[m] / (Ck + 1e-10f);
     }
 }
 
