@@ -87,8 +87,10 @@ def _spread_stats(T, P, x, S):
                 unanimous=int(unanimous.sum()), differs_where_unanimous=int(((P[x] != P[S[0]]) & unanimous).sum()))
 
 
-def test_long_stream_against_the_references_own_spread(golden_dir):
-    """256-sample residual-learning stream (ModelNet40 bank).  tests/golden/g12 holds the reference's OWN loop body run
+@pytest.mark.parametrize('bank', ['modelnet40', 'scanobjectnn'])
+def test_long_stream_against_the_references_own_spread(golden_dir, bank):
+    """256-sample residual-learning streams (ModelNet40 bank, K = 40; ScanObjectNN bank, K = 15 - there the 8-thread run equals the
+    1-thread run bit for bit, the permuted and the fp64 runs agree with it on only 44-48 % of the predictions).  tests/golden/g12 holds the reference's OWN loop body run
     five ways on it (oracle/make_golden.py: a = as is, b = 8 threads, c = feature dimension permuted, d = class order
     permuted - all mathematically the same stream in fp32 - and e = fp64).  Those runs agree to < 1e-3 on samples 0-4,
     are 1.3 apart at sample 5, ~25 apart from sample 64 on, and disagree on 8-22 % of the predictions: the reference is
@@ -96,12 +98,14 @@ def test_long_stream_against_the_references_own_spread(golden_dir):
     The HIP path is therefore held to what the reference holds against itself, every bound calibrated by leave-one-out
     over the five reference runs (no threshold chosen by this test except the stated slack factors):
       1. while the reference runs still agree (their diameter <= 1e-3) HIP is within 1e-3 of run a and predicts the same;
-      2. at EVERY step HIP is no farther from the nearest reference run than twice the runs' own diameter (max(1e-3, .));
+      2. HIP is no farther from the nearest reference run than twice the runs' own diameter (max(1e-3, .)) - at EVERY step on the
+         ModelNet40 stream, as each run is against the other four; on the ScanObjectNN stream one run exceeds that at one step, and HIP
+         may do so no more often than the worst run;
       3. the number of steps where HIP is farther from its nearest run than the diameter (1x) is within the leave-one-out
          range of the reference runs, and so is the literal "farther from SOME run than the diameter" count;
       4. where all five reference runs predict the same class HIP predicts it too, up to the leave-one-out disagreement
          rate of the runs themselves (x2 slack); top-1 accuracy lies in the runs' range (+-5 points)."""
-    g = _load(golden_dir, 'g12_long_stream_modelnet40.npz')
+    g = _load(golden_dir, f'g12_long_stream_{bank}.npz')
     n = g['feat'].shape[0]
     final, pred, eng = _run_hip_stream(g, n, 32)
     V = [str(v) for v in g['variants']]
@@ -119,8 +123,7 @@ def test_long_stream_against_the_references_own_spread(golden_dir):
     assert calm >= 3, calm
     assert (np.abs(final - T['a']).max(1)[:calm] <= 1e-3).all()
     assert np.array_equal(pred[:calm], P['a'][:calm])
-    assert h['over_2x'] == 0, h['over_2x']                                                        # 2
-    assert max(loo[v]['over_2x'] for v in V) == 0                                                 # (the bound is one the runs meet themselves)
+    assert h['over_2x'] <= max(loo[v]['over_2x'] for v in V), (h['over_2x'], [loo[v]['over_2x'] for v in V])        # 2
     assert h['over_nearest'] <= max(loo[v]['over_nearest'] for v in V), (h['over_nearest'], [loo[v]['over_nearest'] for v in V])        # 3
     assert h['over_farthest'] <= max(loo[v]['over_farthest'] for v in V), (h['over_farthest'], [loo[v]['over_farthest'] for v in V])
     worst = max(loo[v]['differs_where_unanimous'] / max(1, loo[v]['unanimous']) for v in V)       # 4
