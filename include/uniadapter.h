@@ -35,7 +35,7 @@ extern "C" {
 #define UA_EWORKSPACE    -4   /* workspace too small                                          */
 #define UA_ELAUNCH       -5   /* hipGetLastError() != hipSuccess after the launch             */
 
-#define UA_VERSION 100        /* 0.1.0 */
+#define UA_VERSION 101        /* 0.1.1: round 2 (ua_fuse_logits_sharded per chunk, ua_tta_state extended, MFMA similarity / alignment entry points) */
 
 int         ua_version(void);
 const char* ua_strerror(int code);
