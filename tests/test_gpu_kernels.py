@@ -236,7 +236,7 @@ def test_fused_cache_step_at_baseline_bank_sizes(ua, K, M, D):
 
 
 @pytest.mark.parametrize('K,M,D,B', [(40, 8, 1024, 40), (15, 4, 512, 5), (7, 16, 1280, 33), (9, 3, 768, 64), (55, 1, 256, 300),
-                                     (1156, 8, 1024, 64), (4096, 16, 1024, 96)])
+                                     (13, 2, 256, 7), (1156, 8, 1024, 64), (1157, 4, 512, 270), (4096, 16, 1024, 96)])
 def test_mfma_similarity_kernel_matches_oracle(ua, K, M, D, B):
     """ua_gmm_loglik_mfma: the batched similarity as a (B x 2D).(2D x KM) product on the matrix cores (SURVEY N14 / section
     8d "batched similarity, GEMM form"; dota_mixture.py:121-156,236-267 with B queries) against the fp64 oracle.
