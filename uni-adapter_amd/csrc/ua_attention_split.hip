@@ -45,11 +45,111 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
     const size_t q_off = (size_t)(h * HD) * 4, k_off = (size_t)(C + h * HD) * 4, v_off = (size_t)(2 * C + h * HD) * 4;
 
     const bool cls_block = qb >= n_qb_patch;
+    if (cls_block) {                                                            // workgroup-uniform
+        // The CLS token of this (cloud, head) is ONE query against G + 1 keys: a 32-query MFMA wave would idle 31 lanes through 17
+        // key tiles while the other three waves only stage (measured: 15 % of the kernel's time at 32 clouds).  Here the 256 threads
+        // take one key each per pass for the scores (fp32 dot products of the exact hi + lo values), a block-wide softmax, and
+        // wave w accumulates p * V over keys w, w+4, ... with one output feature per lane.
+        // (LDS: the key/value tile buffers of the patch path are unused here and are re-used)
+        float* s_q = reinterpret_cast<float*>(&s_k[0][0]);                      // [64]
+        float* s_red = s_q + HD;                                                // [8]
+        float* s_p = s_red + 8;                                                 // scores, then probabilities: [G + 1]
+        float* s_o = reinterpret_cast<float*>(&s_v[0][0]);                      // [32 key slots][64]
+        static_assert(sizeof(s_k) >= (HD + 8 + 1024 + 1) * 4 && sizeof(s_v) >= 32 * HD * 4, "CLS path scratch");
+        const int nkeys = G + 1;
+        const long long qrow = (long long)Bc * G + b;
+        if (tid < HD) {
+            const unsigned char* p = qkv + (size_t)qrow * row_bytes + q_off + (tid >> 5) * 128 + (tid & 31) * 2;
+            s_q[tid] = (float)*reinterpret_cast<const _Float16*>(p) + (float)*reinterpret_cast<const _Float16*>(p + 64);
+        }
+        __syncthreads();
+        // 8 threads per key (8 features each: one 16-byte hi and one 16-byte lo load), 32 keys per pass
+        const int g8 = tid & 7, slot = tid >> 3;
+        const size_t foff = (size_t)(g8 >> 2) * 128 + (size_t)(g8 & 3) * 16;
+        float qf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[j] = s_q[8 * g8 + j];
+        float mloc = -INFINITY;
+        for (int k0 = slot; k0 < nkeys; k0 += 128) {                            // 4 independent keys in flight per thread
+            f16x8 kh[4], kl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = k0 + 32 * u;
+                const long long row = key < G ? (long long)b * G + key : qrow;  // (keys past the end re-read the CLS row; result dropped)
+                const unsigned char* kp = qkv + (size_t)row * row_bytes + k_off + foff;
+                kh[u] = *reinterpret_cast<const f16x8*>(kp);
+                kl[u] = *reinterpret_cast<const f16x8*>(kp + 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = k0 + 32 * u;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __builtin_fmaf((float)kh[u][j] + (float)kl[u][j], qf[j], acc);
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+                if (key < nkeys) {
+                    if (g8 == 0) s_p[key] = acc;
+                    mloc = fmaxf(mloc, acc);
+                }
+            }
+        }
+        mloc = ua::wave_max(mloc);
+        if (lane == 0) s_red[wid] = mloc;
+        __syncthreads();
+        const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float lsum = 0.f;
+        for (int key = tid; key < nkeys; key += 256) {
+            const float pv = __builtin_amdgcn_exp2f((s_p[key] - mx) * c2);      // c2 = hd^-0.5 / s^2 * log2(e) > 0
+            s_p[key] = pv;
+            lsum += pv;
+        }
+        lsum = ua::wave_sum(lsum);
+        if (lane == 0) s_red[4 + wid] = lsum;
+        __syncthreads();
+        const float ltot = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        for (int k0 = slot; k0 < nkeys; k0 += 128) {
+            f16x8 vh[4], vl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = k0 + 32 * u;
+                const long long row = key < G ? (long long)b * G + key : qrow;
+                const unsigned char* vp = qkv + (size_t)row * row_bytes + v_off + foff;
+                vh[u] = *reinterpret_cast<const f16x8*>(vp);
+                vl[u] = *reinterpret_cast<const f16x8*>(vp + 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = k0 + 32 * u;
+                const float pk = key < nkeys ? s_p[key] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(pk, (float)vh[u][j] + (float)vl[u][j], o[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_o[slot * HD + 8 * g8 + j] = o[j];
+        __syncthreads();
+        if (tid < HD) {
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) r += s_o[q * HD + tid];
+            r *= v_inv_scale / ltot;
+            if (out) out[qrow * ldo + h * HD + tid] = r;
+            if (out_split) {
+                const float x = r * out_scale;
+                const _Float16 hi = (_Float16)x;
+                unsigned char* q0 = out_split + (size_t)qrow * ldos * 4 + ua::split_col_off((h * HD + tid) & ~3) + (tid & 3) * 2;
+                *reinterpret_cast<_Float16*>(q0) = hi;
+                *reinterpret_cast<_Float16*>(q0 + 64) = (_Float16)(x - (float)hi);
+            }
+        }
+        return;
+    }
     const int q_local = wid * 32 + li;
-    long long q_row; bool q_valid;
-    if (!cls_block) { q_row = (long long)b * G + qb * 128 + q_local; q_valid = true; }
-    else            { q_row = (long long)Bc * G + b; q_valid = (q_local == 0); }
-    const bool wave_active = !cls_block || wid == 0;
+    const long long q_row = (long long)b * G + qb * 128 + q_local;
+    constexpr bool q_valid = true, wave_active = true;                          // (every wave of a patch block holds 32 real queries)
 
     // Q fragments: k16 step s covers features 16s..16s+15; lane half lh holds 8 of them
     f16x8 qh[4], ql[4];
@@ -222,7 +322,7 @@ extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scal
     UA_CHECK_PTR(qkv); UA_CHECK_ALIGN16(qkv);
     if (!out && !out_split) return UA_EINVAL;
     if (Bc <= 0 || G <= 0 || H <= 0 || !(qkv_scale > 0.f)) return UA_EINVAL;
-    if (hd != HD || G % 128 != 0) return UA_EUNSUPPORTED;
+    if (hd != HD || G % 128 != 0 || G > 1024) return UA_EUNSUPPORTED;
     if (ldqkv % 32 || ldqkv < 3LL * H * HD) return UA_EALIGN;
     if (out && (ldo % 4 || ldo < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out) & 15))) return UA_EALIGN;
     if (out_split && (ldos % 32 || ldos < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out_split) & 15) || !(out_scale > 0.f))) return UA_EALIGN;
