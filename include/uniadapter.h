@@ -35,7 +35,7 @@ extern "C" {
 #define UA_EWORKSPACE    -4   /* workspace too small                                          */
 #define UA_ELAUNCH       -5   /* hipGetLastError() != hipSuccess after the launch             */
 
-#define UA_VERSION 101        /* 0.1.1: round 2 (ua_fuse_logits_sharded per chunk, ua_tta_state extended, MFMA similarity / alignment entry points) */
+#define UA_VERSION 102        /* 0.1.1: round 2 (ua_fuse_logits_sharded per chunk, ua_tta_state extended, MFMA similarity / alignment entry points) */
 
 int         ua_version(void);
 const char* ua_strerror(int code);
@@ -193,7 +193,15 @@ int ua_ball_group(const float* xyz, const float* point_feat, const float* center
  *        out[:, j] = silu(gate)*up, N_out = N/2; timm SwiGLU of EvaBlock)
  *   v += residual[m, n]
  *   C[m,n] = v (if C) ; pool_out[m / pool_rows, n] = max over the row group (pool_rows = 64 or 32)
- *   split_out (optional): the same output as an H32L32 split-precision matrix (see ua_split_f16)  */
+ *   split_out (optional): the same output as an H32L32 split-precision matrix (see ua_split_f16)
+ * LayerNorm folded around the GEMM (ua_gemm_split only; the EvaBlock norm1 / norm2 / SwiGLU ffn_ln, timm eva.py, never
+ * exist as a pass over HBM): LN(a).W0^T = rstd*(a.(gamma (.) W0)^T - mean * rowsum(gamma (.) W0)) + W0.beta, so
+ *   producer: row_stats_out[t*ld_stats + m] = (sum, sum of squares) of the OUTPUT values v[m, :] this launch wrote from
+ *             its t-th tile of 256 input columns (float2; t < ceil(N/256)); ua_row_stats_finalize reduces the tiles to
+ *             (mean, rstd) per row;
+ *   consumer: A holds the UN-normalised rows, W = gamma (.) W0 and bias = b0 + W0.beta (prepared by the caller);
+ *             ln_mean_rstd (M float2) and ln_colsum[n] = sum_k W[n,k] change the first line above to
+ *             v = rstd[m]*(acc - mean[m]*ln_colsum[n]) + (bias[n] + rowgroup_add[..]).                          */
 typedef struct {
     const float* bias;
     const float* scale;
@@ -203,6 +211,8 @@ typedef struct {
     const float* residual;     int64_t ldr;
     float*       pool_out;     int64_t ldp; int32_t pool_rows;
     void*        split_out;    int64_t ld_split; float split_scale;  /* optional H32L32 copy of the output */
+    float*       row_stats_out; int64_t ld_stats;                    /* ua_gemm_split only */
+    const float* ln_mean_rstd;  const float* ln_colsum;              /* ua_gemm_split only */
 } ua_gemm_epilogue;
 
 /* C (M,N) = A (M,K) @ W (N,K)^T with fused epilogue: every Linear / Conv1d(k=1) of the encoder
@@ -232,6 +242,12 @@ int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t rows
 int ua_gemm_split(const void* A, int64_t lda, float a_scale, const void* W, int64_t ldw, float w_scale,
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                   const ua_gemm_epilogue* ep, void* stream);
+
+/* Row statistics for the folded LayerNorm: partials (parts, ld_stats) float2 as written through
+ * ua_gemm_epilogue.row_stats_out -> mean_rstd[m] = (mean, 1/sqrt(var + eps)) over n values per row (biased variance,
+ * F.layer_norm); the tiles are summed in index order in fp64, so the result does not depend on scheduling.          */
+int ua_row_stats_finalize(const float* partials, int32_t parts, int64_t ld_stats, int32_t rows, int32_t n, float eps,
+                          float* mean_rstd, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MFMA (GEMM-form) similarity kernel: DOTA_mix.predict / _log_likelihood for a BATCH of B queries

@@ -834,6 +834,120 @@ def test_gemm_split_epilogues_and_split_output(ua):
     assert (rec - Cd.cpu().double()).abs().max().item() <= 2 ** -20 * ref.abs().max().item()
 
 
+def _unsplit(y, rows, cols, scale):
+    raw = y.cpu().view(torch.float16).reshape(rows, cols // 32, 2, 32)
+    return (raw[:, :, 0].double() + raw[:, :, 1].double()).reshape(rows, cols) / scale
+
+
+@pytest.mark.parametrize('act', [0, 3])
+def test_gemm_split_row_statistics_of_the_output(ua, act):
+    """row_stats_out + ua_row_stats_finalize: per-row (mean, rstd) of what the launch wrote (plain + residual, and SwiGLU with
+    zero-padded hidden columns), ragged row count, partials summed deterministically."""
+    from uni_adapter_amd.lib import GemmEpilogue
+    g = torch.Generator().manual_seed(40 + act)
+    M, K = 700, 96
+    n_real = 330 if act == 3 else 320                                     # SwiGLU: 330 hidden units padded to 352 (= 11 blocks of 32)
+    n_out = 352 if act == 3 else 320
+    N = 2 * n_out if act == 3 else n_out
+    A = torch.randn(M, K, generator=g)
+    if act == 3:
+        Wg = torch.zeros(n_out, K); Wu = torch.zeros(n_out, K); bg = torch.zeros(n_out); bu = torch.zeros(n_out)
+        Wg[:n_real] = torch.randn(n_real, K, generator=g) / 8; Wu[:n_real] = torch.randn(n_real, K, generator=g) / 8
+        bg[:n_real] = torch.randn(n_real, generator=g); bu[:n_real] = torch.randn(n_real, generator=g)
+        # column blocks of 32 gate / 32 up (include/uniadapter.h)
+        W = torch.stack([Wg.reshape(-1, 32, K), Wu.reshape(-1, 32, K)], 1).reshape(N, K)
+        b = torch.stack([bg.reshape(-1, 32), bu.reshape(-1, 32)], 1).reshape(N)
+        ref = torch.nn.functional.silu(A.double() @ Wg.double().T + bg.double()) * (A.double() @ Wu.double().T + bu.double())
+        res = None
+    else:
+        W = torch.randn(N, K, generator=g) / 8; b = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g) * 3 + 0.7
+        ref = A.double() @ W.double().T + b.double() + res.double()
+    As, Ws = _split(ua, dev(A)), _split(ua, dev(W), scale=256.0)
+    e = GemmEpilogue(); keep = [dev(b)]
+    e.bias = keep[0].data_ptr(); e.act = act
+    if res is not None:
+        keep.append(dev(res)); e.residual = keep[-1].data_ptr(); e.ldr = N
+    parts = (N + 255) // 256
+    stats = torch.full((parts, 704, 2), float('nan'), device='cuda'); e.row_stats_out = stats.data_ptr(); e.ld_stats = 704
+    Cs = torch.zeros(M, n_out, device='cuda'); e.split_out = Cs.data_ptr(); e.ld_split = n_out; e.split_scale = 4.0
+    Cd = torch.zeros(M, n_out, device='cuda')
+    ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), n_out, M, N, K, C.byref(e), ua.stream_ptr())
+    assert (Cd.cpu().double() - ref).abs().max().item() < 5e-5
+    assert (_unsplit(Cs, M, n_out, 4.0) - Cd.cpu().double()).abs().max().item() <= 2 ** -20 * ref.abs().max().item()
+    st = stats.cpu().double()[:, :M]
+    assert not torch.isnan(st).any()
+    out = Cd.cpu().double()
+    assert (st[..., 0].sum(0) - out.sum(1)).abs().max().item() <= 1e-5 * out.abs().sum(1).max().item()
+    assert (st[..., 1].sum(0) - (out * out).sum(1)).abs().max().item() <= 1e-5 * (out * out).sum(1).max().item()
+    mr = torch.empty(M, 2, device='cuda')
+    ua.call('ua_row_stats_finalize', stats.data_ptr(), parts, 704, M, n_real, 1e-6, mr.data_ptr(), ua.stream_ptr())
+    o = out[:, :n_real]
+    mean = o.mean(1); rstd = 1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-6)
+    assert (mr[:, 0].cpu().double() - mean).abs().max().item() <= 2e-6 * o.abs().max().item()
+    assert ((mr[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 5e-6
+    # same launch again: bit-identical statistics (no atomics)
+    stats2 = torch.zeros_like(stats); e.row_stats_out = stats2.data_ptr()
+    ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), n_out, M, N, K, C.byref(e), ua.stream_ptr())
+    assert torch.equal(stats2[:, :M], stats[:, :M])
+
+
+@pytest.mark.parametrize('M,N,K,kreal,act', [(700, 320, 1024, 1024, 0), (16416, 1024, 2752, 2730, 0), (513, 704, 1024, 1024, 3)])
+def test_gemm_split_folded_layernorm(ua, M, N, K, kreal, act):
+    """LayerNorm folded into the consumer GEMM (ln_mean_rstd / ln_colsum): equals F.layer_norm(a) @ W0^T + b0 (fp64) as closely as
+    the un-folded pipeline (ua_layernorm_split -> ua_gemm_split) does; rows with a large mean / spread of scales included."""
+    from uni_adapter_amd.lib import GemmEpilogue
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.zeros(M, K)
+    a[:, :kreal] = (torch.randn(M, kreal, generator=g) + 0.8 * torch.randn(M, 1, generator=g)) * torch.exp(torch.randn(M, 1, generator=g))
+    gamma = 1 + 0.2 * torch.randn(kreal, generator=g); beta = 0.3 * torch.randn(kreal, generator=g)
+    W0 = torch.zeros(N, K); W0[:, :kreal] = torch.randn(N, kreal, generator=g) / math.sqrt(kreal); b0 = torch.randn(N, generator=g)
+    res = torch.randn(M, N if act == 0 else N // 2, generator=g)
+    ln = torch.nn.functional.layer_norm(a[:, :kreal].double(), (kreal,), gamma.double(), beta.double(), 1e-6)
+    base = ln @ W0[:, :kreal].double().T + b0.double()
+    if act == 3:
+        bl = base.reshape(M, -1, 2, 32)
+        ref = (torch.nn.functional.silu(bl[:, :, 0]) * bl[:, :, 1]).reshape(M, N // 2)
+    else:
+        ref = base + res.double()
+    n_out = ref.shape[1]
+    # host-side preparation (what point_encoder.py does once per weight)
+    Wf = torch.zeros(N, K); Wf[:, :kreal] = W0[:, :kreal] * gamma
+    ws = min(4096.0, 2.0 ** math.floor(math.log2(30000.0 / Wf.abs().max().item())))
+    hi = (Wf * ws).half(); lo = (Wf * ws - hi.float()).half()
+    colsum = ((hi.double() + lo.double()) / ws).sum(1).float()
+    bias = (b0.double() + W0[:, :kreal].double() @ beta.double()).float()
+    mean = a[:, :kreal].double().mean(1); rstd = 1 / torch.sqrt(a[:, :kreal].double().var(1, unbiased=False) + 1e-6)
+    mr = torch.stack([mean, rstd], 1).float()
+    As, Ws = _split(ua, dev(a), K, 1.0), _split(ua, dev(Wf), K, ws)
+    e = GemmEpilogue(); keep = [dev(bias), dev(mr), dev(colsum), dev(res)]
+    e.bias, e.ln_mean_rstd, e.ln_colsum = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(); e.act = act
+    if act == 0:
+        e.residual = keep[3].data_ptr(); e.ldr = N
+    Cd = torch.zeros(M, n_out, device='cuda')
+    ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, ws, ua.ptr(Cd), n_out, M, N, K, C.byref(e), ua.stream_ptr())
+    # un-folded pipeline
+    y = torch.empty(M, K, device='cuda')
+    ua.call('ua_layernorm_split', ua.ptr(dev(a)), K, ua.ptr(dev(gamma)), ua.ptr(dev(beta)), 1e-6, y.data_ptr(), K, M, kreal, K, 8.0, ua.stream_ptr())
+    W0s = _split(ua, dev(W0), K, ws)
+    e0 = GemmEpilogue(); keep0 = [dev(b0)]; e0.bias = keep0[0].data_ptr(); e0.act = act
+    if act == 0:
+        e0.residual = keep[3].data_ptr(); e0.ldr = N
+    C0 = torch.zeros(M, n_out, device='cuda')
+    ua.call('ua_gemm_split', y.data_ptr(), K, 8.0, W0s.data_ptr(), K, ws, ua.ptr(C0), n_out, M, N, K, C.byref(e0), ua.stream_ptr())
+    e1 = (Cd.cpu().double() - ref).abs(); e0_ = (C0.cpu().double() - ref).abs()
+    print(f'folded max {e1.max():.3e} rms {e1.pow(2).mean().sqrt():.3e} | LN kernel + GEMM max {e0_.max():.3e} rms {e0_.pow(2).mean().sqrt():.3e}')
+    assert e1.pow(2).mean().sqrt().item() <= 2.0 * e0_.pow(2).mean().sqrt().item() + 1e-9
+    assert e1.max().item() <= 3.0 * e0_.max().item() + 1e-7
+
+
+def test_gemm_f32_rejects_the_folded_layernorm(ua):
+    from uni_adapter_amd.lib import GemmEpilogue
+    x = torch.zeros(64, 64, device='cuda'); e = GemmEpilogue(); e.row_stats_out = x.data_ptr(); e.ld_stats = 64
+    with pytest.raises(RuntimeError, match='envelope'):
+        ua.call('ua_gemm', ua.ptr(x), 64, ua.ptr(x), 64, ua.ptr(x), 64, 64, 64, 64, C.byref(e), ua.stream_ptr())
+
+
 def test_layernorm_split_output(ua):
     g = torch.Generator().manual_seed(6)
     rows, cols, pad = 100, 2730, 2752

@@ -244,6 +244,39 @@ def mfma_sim():
             print(f'   B={K:4d} mfma small path incl. query operand + joint: {med * 1e3:8.1f} us (best {mn * 1e3:.1f})')
 
 
+def fold_epi():
+    """Epilogue variants of the encoder's three GEMM shapes at the bench chunk (62 clouds): what the folded LayerNorm adds."""
+    print('== ua_gemm_split epilogue variants (rows = 62 * 513)')
+    M = 62 * 513
+    st = lib.stream_ptr()
+    for N, K, name, act in [(5504, 1024, 'fc1 swiglu', 3), (3072, 1024, 'qkv', 0), (1024, 2752, 'fc2 + residual', 0), (1024, 1024, 'proj + residual', 0)]:
+        A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda') / K ** 0.5
+        As = torch.empty(M, K, device='cuda'); Ws = torch.empty(N, K, device='cuda')
+        lib.call('ua_split_f16', A.data_ptr(), K, As.data_ptr(), K, M, K, K, 1.0, st)
+        lib.call('ua_split_f16', W.data_ptr(), K, Ws.data_ptr(), K, N, K, K, 1024.0, st)
+        n_out = N // 2 if act == 3 else N
+        Cc = torch.empty(M, n_out, device='cuda'); Cs = torch.empty(M, n_out, device='cuda')
+        b = torch.randn(N, device='cuda'); res = torch.randn(M, n_out, device='cuda')
+        stats = torch.empty((N + 255) // 256, M, 2, device='cuda'); mr = torch.rand(M, 2, device='cuda'); cs = torch.randn(N, device='cuda')
+        fl = 2.0 * M * N * K
+        for label, opt in [('fp32 out', dict(c=1)), ('split out', dict(s=1)), ('fp32 + split out', dict(c=1, s=1)), ('split + stats', dict(s=1, st=1)),
+                           ('fp32 + split + stats', dict(c=1, s=1, st=1)), ('fold, split out', dict(s=1, f=1)), ('fold, split + stats', dict(s=1, st=1, f=1)),
+                           ('fold, fp32 + split + stats', dict(c=1, s=1, st=1, f=1))]:
+            e = GemmEpilogue(); e.bias = b.data_ptr(); e.act = act
+            if 'residual' in name:
+                e.residual = res.data_ptr(); e.ldr = n_out
+            if opt.get('s'):
+                e.split_out = Cs.data_ptr(); e.ld_split = n_out; e.split_scale = 1.0
+            if opt.get('st'):
+                e.row_stats_out = stats.data_ptr(); e.ld_stats = M
+            if opt.get('f'):
+                e.ln_mean_rstd = mr.data_ptr(); e.ln_colsum = cs.data_ptr()
+            cp = Cc.data_ptr() if opt.get('c') else None
+            fn = lambda: lib.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 1024.0, cp, n_out, M, N, K, C.byref(e), st)
+            med, mn = timeit(fn, reps=20)
+            print(f'{name:16s} {label:28s} {med * 1e3:8.1f} us (best {mn * 1e3:8.1f})  {fl / med / 1e9:7.1f} TF/s-equiv')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'attn', 'group', 'ln', 'cache', 'replay', 'encoders', 'caches']
     for w in which:

@@ -128,6 +128,9 @@ struct EpiArgs {
     // internal extensions (not in the public ua_gemm_epilogue; used by the MFMA similarity kernel, ua_gmm_loglik_mfma):
     const float* row_scale;        // per-output-row factor applied to the accumulator (operand rows carry their own power-of-two scale)
     float* lse; long long ld_lse; int lse_group;   // act 4: logsumexp over groups of lse_group (4, 8 or 16) consecutive columns -> lse[m, n / group]
+    // LayerNorm folded around the GEMM (split kernel only; see ua_gemm_epilogue in include/uniadapter.h)
+    float2* stats; long long ld_stats;             // out: per (column tile, row) partial (sum, sum of squares) of the output values
+    const float2* ln_mr; const float* ln_c;        // in: per-row (mean, rstd) of A's rows and the row sums of W: v = rstd*(acc - mean*ln_c[n]) + bias[n]
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -166,6 +169,26 @@ __device__ __forceinline__ void stage_64x64_b16(float* stage, const f32x4 (&acc)
                 stage[(ib * 16 + 4 * lq + j) * EP_LD + jb * 16 + l15] = acc[ib0 + ib][jb][j];
 }
 
+// Staging with the folded LayerNorm applied: staged = acc * (as * rstd[row]) - mean[row] * rstd[row] * colsum[col].
+// mr: (mean, rstd) of the 64 rows of this half, lc: column sums of the wave's 64 columns (both in LDS).
+__device__ __forceinline__ void stage_64x64_b16_fold(float* stage, const f32x4 (&acc)[8][4], int ib0, int lane, float as,
+                                                     const float2* mr, const float* lc) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    float c[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) c[jb] = lc[jb * 16 + l15];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 m = mr[ib * 16 + 4 * lq + j];
+            const float a = as * m.y, b = -m.x * m.y;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+                stage[(ib * 16 + 4 * lq + j) * EP_LD + jb * 16 + l15] = __builtin_fmaf(acc[ib0 + ib][jb][j], a, b * c[jb]);
+        }
+}
+
 // float4 epilogue of one staged 64x64 sub-tile owned by one wave.  mbase: first output row;
 // ncol_base: first INPUT column of the sub-tile (multiple of 64).  Every lane handles 4 consecutive
 // columns (c4) of rows lr, lr+4, ...; C is written in 256-byte row segments with 16-byte stores.
@@ -173,7 +196,7 @@ __device__ __forceinline__ void stage_64x64_b16(float* stage, const f32x4 (&acc)
 // template parameter so the activation switch is outside the row loop; the optional operands are
 // wave-uniform (scalar) branches and all row addresses advance by pointer increments.
 template <bool FULL, int ACT>
-__device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+__device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base, float2* part, bool prescaled) {
     // the library is built with -ffp-contract=off for the element-wise cache kernels; here acc*scale + bias and the BN
     // affine may fuse (one rounding instead of two, half the VALU instructions of the row loop)
 #pragma clang fp contract(fast)
@@ -196,7 +219,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
         if (FULL || nout0 + 3 < n_out) *reinterpret_cast<float4*>(q) = v;
         else { if (nout0 < n_out) q[0] = v.x; if (nout0 + 1 < n_out) q[1] = v.y; if (nout0 + 2 < n_out) q[2] = v.z; }
     };
-    const float as = g.acc_scale;
+    const float as = prescaled ? 1.0f : g.acc_scale;               // (folded LayerNorm: the staging step applied acc_scale * rstd already)
     const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
     const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);                 // v = (acc*as + bias + rga) * scale + shift
     const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
@@ -234,6 +257,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
         for (int p = 0; p < 16; ++p)
             if (FULL || m_first + p * 4 < g.M) rs[p] = g.row_scale[m_first + p * 4];
     }
+    const bool have_stats = part != nullptr;                         // wave-uniform
     const bool affine = g.scale || g.shift;
     float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
@@ -279,6 +303,19 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
                 g.lse[(size_t)(m_first + p * 4) * g.ld_lse + ncol0 / G] = out;
         }
         const bool lane_ok = (FULL || m_first + p * 4 < g.M) && active;         // FULL and not SwiGLU: constant true
+        if (have_stats) {
+            // (sum, sum of squares) of this row's 64 (SwiGLU: 32) output columns: 4 columns per lane, 16 lanes per row
+            float4 t = v;
+            if (!lane_ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (!FULL) { if (nout0 >= n_out) t.x = 0.f; if (nout0 + 1 >= n_out) t.y = 0.f; if (nout0 + 2 >= n_out) t.z = 0.f; if (nout0 + 3 >= n_out) t.w = 0.f; }
+            float s1 = (t.x + t.y) + (t.z + t.w);
+            float s2 = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+            s1 += dpp_f<0xB1, 0xF>(s1);  s2 += dpp_f<0xB1, 0xF>(s2);           // quad_perm [1,0,3,2]
+            s1 += dpp_f<0x4E, 0xF>(s1);  s2 += dpp_f<0x4E, 0xF>(s2);           // quad_perm [2,3,0,1]
+            s1 += dpp_f<0x141, 0xF>(s1); s2 += dpp_f<0x141, 0xF>(s2);          // row_half_mirror
+            s1 += dpp_f<0x140, 0xF>(s1); s2 += dpp_f<0x140, 0xF>(s2);          // row_mirror
+            if ((lane & 15) == 0) part[lr + 4 * p] = make_float2(s1, s2);
+        }
         if (FULL && !swiglu) {
             if (have_c) *reinterpret_cast<float4*>(cp + p * cstep) = v;
             if (have_s) {
@@ -325,19 +362,21 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
 }
 
 template <bool FULL>
-__device__ __forceinline__ void epilogue_64x64_act(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
+__device__ __forceinline__ void epilogue_64x64_act(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base, float2* part, bool prescaled) {
     switch (g.act) {                                                 // wave-uniform
-        case 1:  epilogue_64x64_impl<FULL, 1>(g, stage, lane, mbase, ncol_base); break;
-        case 2:  epilogue_64x64_impl<FULL, 2>(g, stage, lane, mbase, ncol_base); break;
-        case 3:  epilogue_64x64_impl<FULL, 3>(g, stage, lane, mbase, ncol_base); break;
-        case 4:  epilogue_64x64_impl<FULL, 4>(g, stage, lane, mbase, ncol_base); break;
-        default: epilogue_64x64_impl<FULL, 0>(g, stage, lane, mbase, ncol_base); break;
+        case 1:  epilogue_64x64_impl<FULL, 1>(g, stage, lane, mbase, ncol_base, part, prescaled); break;
+        case 2:  epilogue_64x64_impl<FULL, 2>(g, stage, lane, mbase, ncol_base, part, prescaled); break;
+        case 3:  epilogue_64x64_impl<FULL, 3>(g, stage, lane, mbase, ncol_base, part, prescaled); break;
+        case 4:  epilogue_64x64_impl<FULL, 4>(g, stage, lane, mbase, ncol_base, part, prescaled); break;
+        default: epilogue_64x64_impl<FULL, 0>(g, stage, lane, mbase, ncol_base, part, prescaled); break;
     }
 }
 
-__device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base) {
-    if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base);   // wave-uniform
-    else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base);
+// part: LDS slots of this wave's 64 rows for the row statistics (stats output requested), else nullptr
+__device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base, float2* part = nullptr,
+                                               bool prescaled = false) {
+    if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base, part, prescaled);   // wave-uniform
+    else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base, part, prescaled);
 }
 
 // Host-side validation + translation of the public epilogue descriptor (shared by both entry points).
@@ -350,6 +389,10 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
         e.act = ep->act; e.residual = ep->residual; e.ldr = ep->ldr;
         e.pool = ep->pool_out; e.ldp = ep->ldp; e.pool_rows = ep->pool_rows;
         e.Cs = reinterpret_cast<unsigned char*>(ep->split_out); e.ldcs = ep->ld_split; e.cs_scale = ep->split_scale;
+        e.stats = reinterpret_cast<float2*>(ep->row_stats_out); e.ld_stats = ep->ld_stats;
+        e.ln_mr = reinterpret_cast<const float2*>(ep->ln_mean_rstd); e.ln_c = ep->ln_colsum;
+        if ((e.ln_mr != nullptr) != (e.ln_c != nullptr)) return UA_EINVAL;
+        if (e.stats && e.ld_stats < M) return UA_EINVAL;
         if (e.act < 0 || e.act > 3) return UA_EINVAL;
         if (e.rga && e.group_rows <= 0) return UA_EINVAL;
         if (e.rga && e.group_rows % 32 != 0) return UA_EUNSUPPORTED;    // the epilogue holds one addend per 32 rows
@@ -366,6 +409,7 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
     if (e.pool && (e.ldp % 4 || mis(e.pool))) return UA_EALIGN;
     if (e.rga && (e.ldg % 4 || mis(e.rga))) return UA_EALIGN;
     if ((e.bias && mis(e.bias)) || (e.scale && mis(e.scale)) || (e.shift && mis(e.shift))) return UA_EALIGN;
+    if ((e.ln_c && mis(e.ln_c)) || (reinterpret_cast<uintptr_t>(e.ln_mr) & 7) || (reinterpret_cast<uintptr_t>(e.stats) & 7)) return UA_EALIGN;
     if (e.Cs) {
         if (mis(e.Cs) || e.ldcs % 32 || e.ldcs < n_out || n_out % 4) return UA_EALIGN;
         if (!(e.cs_scale > 0.f)) return UA_EINVAL;

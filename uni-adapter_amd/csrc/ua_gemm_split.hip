@@ -29,6 +29,8 @@ constexpr int SBM = 256, SBN = 256, SBK = 32;
 constexpr int S_ROW = 128;                           // LDS bytes per slab row: 8 chunks of 16 B (4 hi | 4 lo)
 constexpr int S_TILE = SBM * S_ROW;                  // 32,768 B per operand tile
 constexpr int S_LDS = 8 * 64 * ua::EP_LD * 4;        // 139,264 B: max(main loop 131,072, epilogue staging)
+constexpr int S_LDS_STATS = 8 * 128 * 8;             // + 8,192 B: (sum, sumsq) partials of every wave's 128 rows (row statistics requested)
+constexpr int S_LDS_FOLD = 256 * 8 + 256 * 4;        // + 3,072 B: (mean, rstd) of the tile's rows and the column sums of its columns (folded LayerNorm)
 
 struct SplitArgs {
     const unsigned char* A; const unsigned char* W;
@@ -417,6 +419,19 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     }
 
     const bool full = (m0 + SBM <= g.M) && (n0 + SBN <= g.N);
+    if (B16 && g.ep.ln_mr) {
+        // folded LayerNorm: the tile's per-row (mean, rstd) and per-column sums go straight to LDS beyond the main loop's
+        // buffers (buffer_load ... lds, like the operand tiles): no VGPRs, no wait here - the main loop's first vmcnt wait +
+        // barrier covers them.  Rows / columns past the matrix read as zeros (num_records).
+        extern __shared__ __attribute__((aligned(16))) unsigned char slds0[];
+        const int wb = __builtin_amdgcn_readfirstlane(wid) * 256;                  // this wave's 64 dwords
+        const __amdgpu_buffer_rsrc_t r_mr = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_mr + m0), 0, min(g.M - m0, SBM) * 8, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_mr, (lds_ptr_t)(slds0 + S_LDS + S_LDS_STATS + wb), 4, wb + lane * 4, 0, 0, 0);
+        if (wid < 4) {
+            const __amdgpu_buffer_rsrc_t r_lc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_c + n0), 0, min(g.N - n0, SBN) * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_lc, (lds_ptr_t)(slds0 + S_LDS + S_LDS_STATS + 256 * 8 + wb), 4, wb + lane * 4, 0, 0, 0);
+        }
+    }
     const int swm = __builtin_amdgcn_readfirstlane(wm), swn = __builtin_amdgcn_readfirstlane(wn);
     bool on[4][2];
 #pragma unroll
@@ -445,6 +460,10 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     // epilogue: two 64x64 halves through the wave's LDS staging area (8 x 17,408 B = 139,264 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
     float* stage = reinterpret_cast<float*>(slds) + wid * 64 * ua::EP_LD;
+    float2* part = g.ep.stats ? reinterpret_cast<float2*>(slds + S_LDS) + wid * 128 : nullptr;     // block-uniform
+    const bool fold = B16 && g.ep.ln_mr != nullptr;                                                // block-uniform
+    const float2* s_mr = reinterpret_cast<const float2*>(slds + S_LDS + S_LDS_STATS) + wm * 128;
+    const float* s_lc = reinterpret_cast<const float*>(slds + S_LDS + S_LDS_STATS + 256 * 8) + wn * 64;
 #ifdef UA_SPLIT_TRACE
     unsigned long long es[4] = {0, 0, 0, 0};
 #define UA_ES(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -453,8 +472,10 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #endif
     // (two explicit halves: the accumulator blocks must be indexed statically)
     if (m0 + wm * 128 < g.M) {                                 // wave-uniform
-        if constexpr (B16) ua::stage_64x64_b16(stage, acc, 0, lane);
-        else ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
+        if constexpr (B16) {
+            if (fold) ua::stage_64x64_b16_fold(stage, acc, 0, lane, g.ep.acc_scale, s_mr, s_lc);
+            else ua::stage_64x64_b16(stage, acc, 0, lane);
+        } else ua::stage_64x64(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], li, lh);
         UA_ES(0);
 #if defined(UA_SPLIT_TRACE) && defined(UA_EPI_STORE_ONLY)
         {   // ablation (tools/gemm_trace.py --store-only): the 16 row stores of the sub-tile without LDS reads or arithmetic
@@ -465,18 +486,29 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
             for (int p = 0; p < 16; ++p) *reinterpret_cast<float4*>(cp + (size_t)p * 4 * g.ep.ldc) = v;
         }
 #else
-        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128, n0 + wn * 64);
+        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128, n0 + wn * 64, part, fold);
 #endif
         UA_ES(1);
     }
     if (m0 + wm * 128 + 64 < g.M) {
-        if constexpr (B16) ua::stage_64x64_b16(stage, acc, 4, lane);
-        else ua::stage_64x64(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], li, lh);
+        if constexpr (B16) {
+            if (fold) ua::stage_64x64_b16_fold(stage, acc, 4, lane, g.ep.acc_scale, s_mr + 64, s_lc);
+            else ua::stage_64x64_b16(stage, acc, 4, lane);
+        } else ua::stage_64x64(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], li, lh);
         UA_ES(2);
-        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128 + 64, n0 + wn * 64);
+        ua::epilogue_64x64(g.ep, stage, lane, m0 + wm * 128 + 64, n0 + wn * 64, part ? part + 64 : nullptr, fold);
         UA_ES(3);
     }
 #undef UA_ES
+    if (g.ep.stats) {
+        // row statistics of this tile: the four column waves' partials are added in wave order (deterministic)
+        __syncthreads();
+        if (tid < SBM && m0 + tid < g.M) {
+            const float2* pp = reinterpret_cast<const float2*>(slds + S_LDS) + (tid >> 7) * 4 * 128 + (tid & 127);
+            const float2 a = pp[0], b = pp[128], c = pp[256], d = pp[384];
+            g.ep.stats[(size_t)tn * g.ep.ld_stats + m0 + tid] = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
+        }
+    }
 #ifdef UA_SPLIT_TRACE
     if (g.timeline) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -562,20 +594,47 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
 #ifdef UA_SPLIT_TRACE
     g.trace = g_trace; g.timeline = g_timeline;
 #endif
-    const size_t lds = (size_t)S_LDS;                                 // 139,264 B
+    if (g.ep.ln_mr && sched != 16) return UA_EUNSUPPORTED;            // (the A/B schedules have no folded-LayerNorm staging)
+    const size_t lds = (size_t)S_LDS + (g.ep.stats || g.ep.ln_mr ? S_LDS_STATS + S_LDS_FOLD : 0);   // 139,264 B (+ 11,264)
     static bool attr_set = false;
     if (!attr_set) {
+        const int lds_max = S_LDS + S_LDS_STATS + S_LDS_FOLD;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UA_ELAUNCH;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
         attr_set = true;
     }
     if (sched == 16) hipLaunchKernelGGL(gemm_split_kernel<16>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     else if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     else            hipLaunchKernelGGL(gemm_split_kernel<2>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
+    UA_LAUNCH_CHECK();
+    return UA_OK;
+}
+
+// Row statistics of the folded LayerNorm: (sum, sumsq) partials per column tile -> (mean, rstd) per row
+__global__ void __launch_bounds__(256)
+row_stats_finalize_kernel(const float2* __restrict__ partials, int parts, long long ld, int rows, double inv_n, double eps,
+                          float2* __restrict__ mean_rstd) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0, q = 0.0;
+    for (int t = 0; t < parts; ++t) { const float2 v = partials[(size_t)t * ld + r]; s += (double)v.x; q += (double)v.y; }
+    const double mean = s * inv_n;
+    const double var = fmax(q * inv_n - mean * mean, 0.0);           // biased variance (F.layer_norm)
+    mean_rstd[r] = make_float2((float)mean, (float)(1.0 / sqrt(var + eps)));
+}
+
+extern "C" int ua_row_stats_finalize(const float* partials, int32_t parts, int64_t ld_stats, int32_t rows, int32_t n, float eps,
+                                     float* mean_rstd, void* stream) {
+    UA_CHECK_PTR(partials); UA_CHECK_PTR(mean_rstd);
+    if (parts <= 0 || rows <= 0 || n <= 0 || ld_stats < rows || !(eps >= 0.f)) return UA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(partials) & 7) || (reinterpret_cast<uintptr_t>(mean_rstd) & 7)) return UA_EALIGN;
+    hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, ua::as_stream(stream),
+                       reinterpret_cast<const float2*>(partials), parts, (long long)ld_stats, rows, 1.0 / n, (double)eps,
+                       reinterpret_cast<float2*>(mean_rstd));
     UA_LAUNCH_CHECK();
     return UA_OK;
 }

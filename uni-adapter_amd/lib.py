@@ -28,7 +28,8 @@ class GemmEpilogue(C.Structure):
                 ('act', _i32),
                 ('residual', _p), ('ldr', _i64),
                 ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32),
-                ('split_out', _p), ('ld_split', _i64), ('split_scale', _f)]
+                ('split_out', _p), ('ld_split', _i64), ('split_scale', _f),
+                ('row_stats_out', _p), ('ld_stats', _i64), ('ln_mean_rstd', _p), ('ln_colsum', _p)]
 
 
 class TtaState(C.Structure):
@@ -85,6 +86,7 @@ SIGNATURES = {
     'ua_layernorm_split': [_p, _i64, _p, _p, _f, _p, _i64, _i32, _i32, _i32, _f, _p],
     'ua_split_f16': [_p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p],
     'ua_gemm_split': [_p, _i64, _f, _p, _i64, _f, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
+    'ua_row_stats_finalize': [_p, _i32, _i64, _i32, _i32, _f, _p, _p],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
     'ua_attention_split': [_p, _i64, _f, _p, _i64, _p, _i64, _f, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],

@@ -12,6 +12,7 @@ row Bc*G+b, so every big GEMM sees Bc*G (a multiple of 128) rows plus one thin t
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -38,6 +39,7 @@ class GemmProfiler:
 
 
 PROFILER = None          # set to a GemmProfiler to time every GEMM launch
+X_SPLIT_SCALE = 1.0      # power-of-two scale of the residual stream's split copy (folded LayerNorms): fp16 'hi' overflows at |x| > 65504
 
 
 class SplitW:
@@ -56,6 +58,24 @@ class SplitW:
                  lib.stream_ptr())
 
 
+def _fold_layernorm(w, bias, gamma, beta):
+    """LayerNorm folded into the Linear that consumes it (include/uniadapter.h, ua_gemm_epilogue):
+    LN(a) @ w^T + bias = rstd * (a @ (gamma * w)^T - mean * colsum) + (bias + w @ beta).
+    w (N, K >= len(gamma)) with zero columns beyond len(gamma).  Returns (SplitW(gamma * w), folded bias, colsum);
+    colsum is taken over the values the matrix cores multiply (hi + lo of the scaled weights), so the mean term cancels
+    against the product exactly as computed."""
+    k0 = gamma.numel()
+    wf = w.clone()
+    wf[:, :k0] *= gamma
+    bf = (bias.double() + w[:, :k0].double() @ beta.double()).float().contiguous()
+    sw = SplitW(wf)
+    q = wf * sw.scale
+    hi = q.half()
+    lo = (q - hi.float()).half()
+    colsum = ((hi.double() + lo.double()).sum(1) / sw.scale).float().contiguous()
+    return sw, bf, colsum
+
+
 def _act_scale(bound):
     """Power-of-two scale for a split activation whose magnitude is bounded by `bound`."""
     return float(min(16.0, 2.0 ** math.floor(math.log2(30000.0 / max(bound, 1e-30)))))
@@ -63,7 +83,7 @@ def _act_scale(bound):
 
 def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgroup_add=None, ldg=0,
           group_rows=0, act=0, residual=None, ldr=0, pool_out=None, ldp=0, pool_rows=0, alg_flops=None,
-          split_out=None, ld_split=0, split_scale=1.0, a_scale=None):
+          split_out=None, ld_split=0, split_scale=1.0, a_scale=None, stats_out=None, ln_mr=None, ln_colsum=None):
     """C (M,N) = A (M,K) @ W (N,K)^T + epilogue; all tensors already on device.
     W is an fp32 tensor (exact-f32 MFMA kernel, A fp32) or a SplitW (3xf16-split MFMA kernel, A an
     H32L32 split matrix with scale `a_scale`).  `split_out`: also/only emit the output in split form.
@@ -80,6 +100,10 @@ def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgr
     e.ldr = ldr
     e.pool_out = pool_out.data_ptr() if pool_out is not None else None
     e.ldp, e.pool_rows = ldp, pool_rows
+    if stats_out is not None:                      # (parts, rows, 2) partial row statistics of the output
+        e.row_stats_out, e.ld_stats = stats_out.data_ptr(), stats_out.shape[1]
+    if ln_mr is not None:                          # folded LayerNorm on the A side
+        e.ln_mean_rstd, e.ln_colsum = ln_mr.data_ptr(), ln_colsum.data_ptr()
     prof = PROFILER
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,6 +119,10 @@ def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgr
     if prof is not None:
         ev1.record()
         prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K, kind))
+
+
+def _row_stats(stats, n_parts, rows, n, eps, out):
+    lib.call('ua_row_stats_finalize', stats.data_ptr(), n_parts, stats.shape[1], rows, n, eps, out.data_ptr(), lib.stream_ptr())
 
 
 def _ln(x, ldx, w, b, eps, y, ldy, rows, cols, cols_pad, split_scale=None):
@@ -122,7 +150,8 @@ class PointcloudEncoder(nn.Module):
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_group: int, group_size: int, num_heads: int,
                  device=None, prefix: str = 'point_encoder.', ln_eps: float = 1e-6, bn_eps: float = 1e-5,
                  fps_start: int = 0, fps_skip_eps: float = 1e-3, pe_clouds: int = 8, precision: str = 'f32',
-                 variant: str = 'uni3d', projection: Optional[torch.Tensor] = None, ball_radius: float = 0.2):
+                 variant: str = 'uni3d', projection: Optional[torch.Tensor] = None, ball_radius: float = 0.2,
+                 fold_layernorm: Optional[bool] = None):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError('uni_adapter_amd.PointcloudEncoder needs a HIP device (MI355X); no CPU path')
@@ -134,6 +163,11 @@ class PointcloudEncoder(nn.Module):
             raise ValueError("precision must be 'f32' (exact-f32 MFMA) or 'split' (3xf16-split MFMA, fp32-accurate)")
         self.precision = precision
         sp = precision == 'split'
+        # split mode: the blocks' LayerNorms are folded into the GEMMs either side of them (no LN pass over HBM);
+        # UA_FOLD_LN=0 / fold_layernorm=False keeps the LN kernels (A/B aid)
+        if fold_layernorm is None:
+            fold_layernorm = os.environ.get('UA_FOLD_LN', '1') != '0'
+        self.fold_ln = bool(fold_layernorm) and sp
         if self.group_size not in (32, 64):
             raise NotImplementedError('patch-embed max-pool epilogue is built for group sizes 64 (Uni3D) and 32 (PointBERT)')
         if variant not in ('uni3d', 'ulip', 'openshape'):
@@ -279,6 +313,16 @@ class PointcloudEncoder(nn.Module):
             b.mn_w, b.mn_b = (d(g('mlp.norm.weight')), d(g('mlp.norm.bias'))) if has('mlp.norm.weight') else (None, None)
             b.w2 = d(torch.nn.functional.pad(g('mlp.fc2.weight'), (0, Hp - H))); b.b2 = d(g('mlp.fc2.bias'))
             b.mn_scale = _act_scale(math.sqrt(H) * float(b.mn_w.abs().max()) + float(b.mn_b.abs().max())) if b.mn_w is not None else 1.0
+            if self.fold_ln:
+                # norm1 -> qkv (not for block 0, whose input no GEMM produced, nor for ULIP, which adds pos in between),
+                # norm2 -> fc1, ffn sub-LN -> fc2
+                b.f_qkv = _fold_layernorm(b.wqkv, b.bqkv, b.n1w, b.n1b) if (i > 0 and variant != 'ulip') else None
+                b.f_w1 = _fold_layernorm(b.w1, b.b1, b.n2w, b.n2b)
+                b.f_w2 = _fold_layernorm(b.w2, b.b2, b.mn_w, b.mn_b) if b.mn_w is not None else None
+                # static bound of the un-normalised hidden activation act(a)[*b]: |a_n| <= |LN(x)|_2 |w_n|_2 + |bias_n|
+                lnb = math.sqrt(Cd) * float(b.n2w.abs().max()) + float(b.n2b.norm())
+                ab = lnb * float(b.w1.norm(dim=1).max()) + float(b.b1.abs().max())
+                b.hraw_scale = _act_scale(ab * ab if b.act == ACT_SWIGLU else ab)
             if sp:
                 b.wqkv, b.wproj, b.w1, b.w2 = SplitW(b.wqkv), SplitW(b.wproj), SplitW(b.w1), SplitW(b.w2)
             self.blocks.append(b)
@@ -306,6 +350,7 @@ class PointcloudEncoder(nn.Module):
                       hid=e(rows, Hp), hidn=e(rows, Hp))
             for i, (wc, _, _, _) in enumerate(self.sa[:-1]):
                 ws[f'sa{i}'] = e(Mp, wc.shape[0])
+            self._fold_workspace(ws, rows, Cd, Hp)
             self._ws[key] = ws
             return ws
         ws = dict(
@@ -314,8 +359,17 @@ class PointcloudEncoder(nn.Module):
             h3=e(Mp, self.n3), tok=e(Bc * G, self.enc_dim), tokc=e(Bc * G, Cd), posh=e(Bc * G, 128),
             pos=e(Bc * G, Cd), x=e(rows, Cd), h=e(rows, Cd), qkv=e(rows, 3 * Cd), att=e(rows, Cd),
             hid=e(rows, Hp), hidn=e(rows, Hp), cls=e(Bc, Cd), cls2=e(Bc, Cd), out=e(Bc, self.embed_dim))
+        self._fold_workspace(ws, rows, Cd, Hp)
         self._ws[key] = ws
         return ws
+
+    def _fold_workspace(self, ws, rows, Cd, Hp):
+        """Buffers of the folded LayerNorms: the residual stream in split form, partial and final row statistics."""
+        if not self.fold_ln:
+            return
+        e = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
+        ws.update(xs=e(rows, Cd), st_x=e((Cd + 255) // 256, rows, 2), st_h=e((2 * Hp + 255) // 256, rows, 2),
+                  mr_x=e(rows, 2), mr_h=e(rows, 2))
 
     @torch.no_grad()
     def _run_blocks(self, w, Bc):
@@ -328,14 +382,21 @@ class PointcloudEncoder(nn.Module):
         rows = Mg + Bc
         x = w['x']
         first = True
-        for b in self.blocks:
+        nb = len(self.blocks)
+        for bi, b in enumerate(self.blocks):
             if self.variant == 'ulip' and not first:      # x = block(x + pos) in every block (pointbert/point_encoder.py:95-98)
                 lib.call('ua_add_pos', x.data_ptr(), w['pos'].data_ptr(), self.cls_pos.data_ptr(), Bc, G, Cd, st)
             first = False
-            # split mode: every GEMM operand is an H32L32 pair written directly by its producer (LN
-            # kernel) or converted once (attention output); x, qkv and the SwiGLU hidden stay fp32.
-            s1 = b.ln1_scale if sp else None
-            _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)
+            fold = self.fold_ln
+            # split mode: every GEMM operand is an H32L32 pair written directly by its producer (attention, a GEMM epilogue or -
+            # without the folded LayerNorms - the LN kernel); x stays fp32, q/k/v and the hidden activation exist only in split form.
+            # Folded LayerNorms: the GEMM that produces x (or the hidden activation) also writes it in split form with per-row
+            # (sum, sumsq) partials; the consuming GEMM multiplies the un-normalised rows by gamma (.) W and applies mean / rstd
+            # in its epilogue (include/uniadapter.h, ua_gemm_epilogue), so no LayerNorm pass over HBM is left.
+            fq = b.f_qkv if fold else None
+            if fq is None:
+                s1 = b.ln1_scale if sp else None
+                _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)
             if not sp:
                 _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv)
                 lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
@@ -345,8 +406,12 @@ class PointcloudEncoder(nn.Module):
                     att = w['h']
             else:
                 # q/k/v only ever exist as a split matrix; attention writes its result in split form too
-                _gemm(w['h'], Cd, b.wqkv, None, 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv, a_scale=s1,
-                      split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0)
+                if fq is None:
+                    _gemm(w['h'], Cd, b.wqkv, None, 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv, a_scale=s1,
+                          split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0)
+                else:
+                    _gemm(w['xs'], Cd, fq[0], None, 3 * Cd, rows, 3 * Cd, Cd, bias=fq[1], a_scale=X_SPLIT_SCALE,
+                          split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0, ln_mr=w['mr_x'], ln_colsum=fq[2])
                 if b.an_w is None:
                     lib.call('ua_attention_split', w['qkv'].data_ptr(), 3 * Cd, 1.0, None, 0, w['h'].data_ptr(), Cd, 1.0,
                              Bc, G, Hh, Cd // Hh, st)
@@ -357,11 +422,37 @@ class PointcloudEncoder(nn.Module):
                     s_att = _act_scale(math.sqrt(Cd) * float(b.an_w.abs().max()) + float(b.an_b.abs().max()))
                     _ln(w['att'], Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s_att)
                     att = w['h']
+            Hp = b.Hp
+            ld_h = w['hid'].stride(0)
+            if fold:
+                _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att,
+                      split_out=w['xs'], ld_split=Cd, split_scale=X_SPLIT_SCALE, stats_out=w['st_x'])
+                _row_stats(w['st_x'], (Cd + 255) // 256, rows, Cd, self.ln_eps, w['mr_x'])
+                n1 = 2 * Hp if b.act == ACT_SWIGLU else Hp
+                fl1 = (4.0 if b.act == ACT_SWIGLU else 2.0) * rows * b.H * Cd
+                f2 = b.f_w2
+                if f2 is not None:
+                    # the hidden activation leaves the fc1 GEMM un-normalised, in split form, with its row statistics
+                    _gemm(w['xs'], Cd, b.f_w1[0], None, ld_h, rows, n1, Cd, bias=b.f_w1[1], act=b.act, alg_flops=fl1, a_scale=X_SPLIT_SCALE,
+                          ln_mr=w['mr_x'], ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale,
+                          stats_out=w['st_h'])
+                    _row_stats(w['st_h'], (n1 + 255) // 256, rows, b.H, self.ln_eps, w['mr_h'])
+                    w2, b2, kw = f2[0], f2[1], dict(ln_mr=w['mr_h'], ln_colsum=f2[2])
+                else:
+                    _gemm(w['xs'], Cd, b.f_w1[0], None, ld_h, rows, n1, Cd, bias=b.f_w1[1], act=b.act, alg_flops=fl1, a_scale=X_SPLIT_SCALE,
+                          ln_mr=w['mr_x'], ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale)
+                    w2, b2, kw = b.w2, b.b2, {}
+                last = bi == nb - 1 or self.blocks[bi + 1].f_qkv is None      # the next block runs its own norm1 kernel on x
+                if not last:
+                    kw.update(split_out=w['xs'], ld_split=Cd, split_scale=X_SPLIT_SCALE, stats_out=w['st_x'])
+                _gemm(w['hidn'], ld_h, w2, x, Cd, rows, Cd, Hp, bias=b2, scale=b.gamma2, residual=x, ldr=Cd,
+                      alg_flops=2.0 * rows * Cd * b.H, a_scale=b.hraw_scale, **kw)
+                if not last:
+                    _row_stats(w['st_x'], (Cd + 255) // 256, rows, Cd, self.ln_eps, w['mr_x'])
+                continue
             _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att)
             s2 = b.ln2_scale if sp else None
             _ln(x, Cd, b.n2w, b.n2b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s2)
-            Hp = b.Hp
-            ld_h = w['hid'].stride(0)
             if b.act == ACT_SWIGLU:
                 _gemm(w['h'], Cd, b.w1, w['hid'], ld_h, rows, 2 * Hp, Cd, bias=b.b1, act=ACT_SWIGLU, alg_flops=4.0 * rows * b.H * Cd, a_scale=s2)
             else:
