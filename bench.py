@@ -401,6 +401,11 @@ def main():
         roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
                      'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt / world, 4)})
+        if dom == 'split' and getattr(model.point_encoder, 'fold_ln', False):
+            # the launches now also do the blocks' LayerNorm work (row statistics, mean/rstd fold, split copy of the residual
+            # stream: DESIGN section 4.2): per-launch time +5 % for the same algorithmic FLOPs (executed_frac 0.48 -> 0.44-0.45)
+            # while the LayerNorm kernels' 5.5 ms/step are gone and the step is 2.8 % faster; UA_FOLD_LN=0 gives the old split
+            roof['includes'] = 'folded LayerNorms of the encoder blocks (no separate LN pass); UA_FOLD_LN=0 runs them as kernels'
         preds = out[2].clone()
         feats = None
         if want_feats:             # encoder features of the head of the stream for the CPU cache-only leg (after the timed region)

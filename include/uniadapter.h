@@ -201,7 +201,10 @@ int ua_ball_group(const float* xyz, const float* point_feat, const float* center
  *             (mean, rstd) per row;
  *   consumer: A holds the UN-normalised rows, W = gamma (.) W0 and bias = b0 + W0.beta (prepared by the caller);
  *             ln_mean_rstd (M float2) and ln_colsum[n] = sum_k W[n,k] change the first line above to
- *             v = rstd[m]*(acc - mean[m]*ln_colsum[n]) + (bias[n] + rowgroup_add[..]).                          */
+ *             v = rstd[m]*(acc - mean[m]*ln_colsum[n]) + (bias[n] + rowgroup_add[..]).
+ *             Instead of ln_mean_rstd the consumer can take the producer's partials directly (ln_stats_in: (ln_parts,
+ *             ln_stats_ld) float2 with ln_parts <= 4, ln_n values per row, ln_eps) and reduce them itself - the same
+ *             arithmetic as ua_row_stats_finalize, bit-identical results, one launch less.                        */
 typedef struct {
     const float* bias;
     const float* scale;
@@ -213,6 +216,7 @@ typedef struct {
     void*        split_out;    int64_t ld_split; float split_scale;  /* optional H32L32 copy of the output */
     float*       row_stats_out; int64_t ld_stats;                    /* ua_gemm_split only */
     const float* ln_mean_rstd;  const float* ln_colsum;              /* ua_gemm_split only */
+    const float* ln_stats_in;   int64_t ln_stats_ld; int32_t ln_parts; int32_t ln_n; float ln_eps;   /* ua_gemm_split only */
 } ua_gemm_epilogue;
 
 /* C (M,N) = A (M,K) @ W (N,K)^T with fused epilogue: every Linear / Conv1d(k=1) of the encoder

@@ -88,6 +88,20 @@ def test_bad_arguments_return_codes_without_gpu():
         lib.call('ua_class_shard_pack', p16, p16, 5, 2, 4, p16, None)
     with pytest.raises(RuntimeError, match='invalid argument'):
         lib.call('ua_fuse_logits_sharded', p16, p16, 2, 1, 4, 9, 2, 0.02, 0.1, 1, None, p16, None, None, None, None)
+    # folded LayerNorm: mean/rstd without column sums, statistics pitch shorter than M, finalize with parts = 0 / ld < rows
+    e = lib.GemmEpilogue(); e.ln_mean_rstd = p16
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gemm_split', p16, 64, 1.0, p16, 64, 1.0, p16, 64, 64, 64, 64, ctypes.byref(e), None)
+    e = lib.GemmEpilogue(); e.row_stats_out = p16; e.ld_stats = 32
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_gemm_split', p16, 64, 1.0, p16, 64, 1.0, p16, 64, 64, 64, 64, ctypes.byref(e), None)
+    e = lib.GemmEpilogue(); e.row_stats_out = p16; e.ld_stats = 64
+    with pytest.raises(RuntimeError, match='envelope'):      # exact-f32 kernel has no folded LayerNorm
+        lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 64, 64, 64, ctypes.byref(e), None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_row_stats_finalize', p16, 0, 64, 64, 1024, 1e-6, p16, None)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        lib.call('ua_row_stats_finalize', p16, 4, 32, 64, 1024, 1e-6, p16, None)
     e = lib.GemmEpilogue(); e.rowgroup_add = p16; e.ldg = 64; e.group_rows = 48
     with pytest.raises(RuntimeError, match='envelope'):
         lib.call('ua_gemm', p16, 64, p16, 64, p16, 64, 96, 64, 64, ctypes.byref(e), None)

@@ -941,6 +941,41 @@ def test_gemm_split_folded_layernorm(ua, M, N, K, kreal, act):
     assert e1.max().item() <= 3.0 * e0_.max().item() + 1e-7
 
 
+@pytest.mark.parametrize('parts', [1, 4])
+def test_gemm_split_folded_layernorm_from_the_producers_partials(ua, parts):
+    """ln_stats_in (the consumer reduces up to 4 tiles of (sum, sumsq) itself) == ua_row_stats_finalize + ln_mean_rstd, bit for bit."""
+    from uni_adapter_amd.lib import GemmEpilogue
+    g = torch.Generator().manual_seed(70 + parts)
+    M, N, K = 777, 384, 256
+    a = torch.randn(M, K, generator=g) * 2 + 0.5
+    W = torch.randn(N, K, generator=g) / 16; bias = torch.randn(N, generator=g); colsum = W.sum(1)
+    ld = M + 3
+    st = torch.zeros(parts, ld, 2)
+    for p_, cols in enumerate(torch.arange(K).chunk(parts)):
+        st[p_, :M, 0] = a[:, cols].sum(1); st[p_, :M, 1] = (a[:, cols] ** 2).sum(1)
+    std = dev(st)
+    mr = torch.empty(M, 2, device='cuda')
+    ua.call('ua_row_stats_finalize', std.data_ptr(), parts, ld, M, K, 1e-6, mr.data_ptr(), ua.stream_ptr())
+    As, Ws = _split(ua, dev(a)), _split(ua, dev(W), scale=256.0)
+    keep = [dev(bias), dev(colsum)]
+    outs = []
+    for mode in (0, 1):
+        e = GemmEpilogue(); e.bias = keep[0].data_ptr(); e.ln_colsum = keep[1].data_ptr()
+        if mode == 0:
+            e.ln_mean_rstd = mr.data_ptr()
+        else:
+            e.ln_stats_in = std.data_ptr(); e.ln_stats_ld = ld; e.ln_parts = parts; e.ln_n = K; e.ln_eps = 1e-6
+        Cd = torch.zeros(M, N, device='cuda')
+        ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
+        outs.append(Cd.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.functional.layer_norm(a.double(), (K,), None, None, 1e-6) @ W.double().T + bias.double()
+    assert (outs[1].double() - ref).abs().max().item() < 5e-5
+    e = GemmEpilogue(); e.ln_colsum = keep[1].data_ptr(); e.ln_stats_in = std.data_ptr(); e.ln_stats_ld = ld; e.ln_parts = 5; e.ln_n = K
+    with pytest.raises(RuntimeError, match='envelope'):
+        ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
+
+
 def test_gemm_f32_rejects_the_folded_layernorm(ua):
     from uni_adapter_amd.lib import GemmEpilogue
     x = torch.zeros(64, 64, device='cuda'); e = GemmEpilogue(); e.row_stats_out = x.data_ptr(); e.ld_stats = 64

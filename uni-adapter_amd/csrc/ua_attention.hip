@@ -33,8 +33,16 @@ attention_kernel(const float* __restrict__ qkv, long long ldqkv, float* __restri
     __shared__ __attribute__((aligned(16))) float s_k[2][KT * K_LD];
     __shared__ __attribute__((aligned(16))) float s_v[2][KT * V_LD];
     const int C = H * HD;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int n_qb_patch = G / 128;                       // query blocks of patch tokens
+    // XCD-aware block order (see attention_split_kernel): ids congruent mod 8 walk the query blocks of one (cloud, head)
+    // pair, so the pair's K and V are fetched by one XCD's L2 instead of up to five
+    int qb, pair;
+    {
+        const int nq = n_qb_patch + 1, L = blockIdx.x;
+        if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
+        else { pair = L / nq; qb = L % nq; }
+    }
+    const int h = pair % H, b = pair / H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -169,8 +177,8 @@ extern "C" int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t
     if (hd != HD || G % 128 != 0) return UA_EUNSUPPORTED;
     if (ldqkv % 4 || ldo % 4) return UA_EALIGN;
     if (ldqkv < 3LL * H * HD || ldo < (int64_t)H * HD) return UA_EINVAL;
-    if (H > 65535 || Bc > 65535) return UA_EUNSUPPORTED;
-    dim3 grid(G / 128 + 1, H, Bc);
+    if ((long long)(G / 128 + 1) * H * Bc > 0x7fffffffLL) return UA_EUNSUPPORTED;
+    dim3 grid((unsigned)(G / 128 + 1) * H * Bc);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, ua::as_stream(stream),
                        qkv, (long long)ldqkv, out, (long long)ldo, Bc, G, H);
     UA_LAUNCH_CHECK();

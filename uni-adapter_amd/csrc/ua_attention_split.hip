@@ -37,8 +37,18 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char s_v[2][KT * VROW];
     const int C = H * HD;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, and the query blocks of one
+    // (cloud, head) pair all read that pair's K and V (263 KB at G = 512): with the pair's blocks on adjacent ids every
+    // XCD's L2 fetched them separately (measured: 3.0x the algorithmic traffic, L2 hit rate 0.37, 5.2 TB/s - the kernel
+    // was fabric-bound).  Here ids congruent mod 8 walk the blocks of one pair, then the next pair of the same XCD.
     const int n_qb_patch = G / 128;
+    int qb, pair;
+    {
+        const int nq = n_qb_patch + 1, L = blockIdx.x;
+        if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
+        else { pair = L / nq; qb = L % nq; }
+    }
+    const int h = pair % H, b = pair / H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const size_t row_bytes = (size_t)ldqkv * 4;
@@ -326,8 +336,8 @@ extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scal
     if (ldqkv % 32 || ldqkv < 3LL * H * HD) return UA_EALIGN;
     if (out && (ldo % 4 || ldo < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out) & 15))) return UA_EALIGN;
     if (out_split && (ldos % 32 || ldos < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out_split) & 15) || !(out_scale > 0.f))) return UA_EALIGN;
-    if (H > 65535 || Bc > 65535) return UA_EUNSUPPORTED;
-    dim3 grid(G / 128 + 1, H, Bc);
+    if ((long long)(G / 128 + 1) * H * Bc > 0x7fffffffLL) return UA_EUNSUPPORTED;
+    dim3 grid((unsigned)(G / 128 + 1) * H * Bc);
     const float c_scale = (0.125f / (qkv_scale * qkv_scale)) * 1.44269504088896340736f;   // hd^-0.5 / s^2 * log2(e)
     hipLaunchKernelGGL(attention_split_kernel, grid, dim3(256), 0, ua::as_stream(stream),
                        reinterpret_cast<const unsigned char*>(qkv), (long long)ldqkv, c_scale, 1.0f / qkv_scale,

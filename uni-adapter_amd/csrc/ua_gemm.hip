@@ -184,7 +184,7 @@ extern "C" int ua_gemm(const float* A, int64_t lda, const float* W, int64_t ldw,
     GemmArgs g{};
     g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     if (int e = ua::fill_epi(g.ep, ep, M, N, C, ldc)) return e;
-    if (g.ep.stats || g.ep.ln_mr) return UA_EUNSUPPORTED;           // the folded LayerNorm exists in the split kernel only
+    if (g.ep.stats || g.ep.ln_mr || g.ep.ln_in) return UA_EUNSUPPORTED;           // the folded LayerNorm exists in the split kernel only
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     g.tiles_n = tiles_n; g.n_tiles = tiles_m * tiles_n;
     const size_t lds = (size_t)4 * TILE_F * sizeof(float);           // 73,728 B

@@ -131,6 +131,7 @@ struct EpiArgs {
     // LayerNorm folded around the GEMM (split kernel only; see ua_gemm_epilogue in include/uniadapter.h)
     float2* stats; long long ld_stats;             // out: per (column tile, row) partial (sum, sum of squares) of the output values
     const float2* ln_mr; const float* ln_c;        // in: per-row (mean, rstd) of A's rows and the row sums of W: v = rstd*(acc - mean*ln_c[n]) + bias[n]
+    const float2* ln_in; long long ln_in_ld; int ln_parts; double ln_inv_n, ln_eps;   // in (instead of ln_mr): the producer's partials, reduced by the consumer
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -391,7 +392,14 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
         e.Cs = reinterpret_cast<unsigned char*>(ep->split_out); e.ldcs = ep->ld_split; e.cs_scale = ep->split_scale;
         e.stats = reinterpret_cast<float2*>(ep->row_stats_out); e.ld_stats = ep->ld_stats;
         e.ln_mr = reinterpret_cast<const float2*>(ep->ln_mean_rstd); e.ln_c = ep->ln_colsum;
-        if ((e.ln_mr != nullptr) != (e.ln_c != nullptr)) return UA_EINVAL;
+        e.ln_in = reinterpret_cast<const float2*>(ep->ln_stats_in); e.ln_in_ld = ep->ln_stats_ld; e.ln_parts = ep->ln_parts;
+        if (e.ln_in && e.ln_mr) return UA_EINVAL;
+        if ((e.ln_mr != nullptr || e.ln_in != nullptr) != (e.ln_c != nullptr)) return UA_EINVAL;
+        if (e.ln_in) {
+            if (ep->ln_parts < 1 || ep->ln_n < 1 || ep->ln_stats_ld < M || !(ep->ln_eps >= 0.f)) return UA_EINVAL;
+            if (ep->ln_parts > 4) return UA_EUNSUPPORTED;              // (LDS budget; more tiles go through ua_row_stats_finalize)
+            e.ln_inv_n = 1.0 / ep->ln_n; e.ln_eps = (double)ep->ln_eps;
+        }
         if (e.stats && e.ld_stats < M) return UA_EINVAL;
         if (e.act < 0 || e.act > 3) return UA_EINVAL;
         if (e.rga && e.group_rows <= 0) return UA_EINVAL;
@@ -409,7 +417,8 @@ static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N,
     if (e.pool && (e.ldp % 4 || mis(e.pool))) return UA_EALIGN;
     if (e.rga && (e.ldg % 4 || mis(e.rga))) return UA_EALIGN;
     if ((e.bias && mis(e.bias)) || (e.scale && mis(e.scale)) || (e.shift && mis(e.shift))) return UA_EALIGN;
-    if ((e.ln_c && mis(e.ln_c)) || (reinterpret_cast<uintptr_t>(e.ln_mr) & 7) || (reinterpret_cast<uintptr_t>(e.stats) & 7)) return UA_EALIGN;
+    if ((e.ln_c && mis(e.ln_c)) || (reinterpret_cast<uintptr_t>(e.ln_mr) & 7) || (reinterpret_cast<uintptr_t>(e.stats) & 7) ||
+        (reinterpret_cast<uintptr_t>(e.ln_in) & 7)) return UA_EALIGN;
     if (e.Cs) {
         if (mis(e.Cs) || e.ldcs % 32 || e.ldcs < n_out || n_out % 4) return UA_EALIGN;
         if (!(e.cs_scale > 0.f)) return UA_EINVAL;

@@ -419,14 +419,24 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     }
 
     const bool full = (m0 + SBM <= g.M) && (n0 + SBN <= g.N);
-    if (B16 && g.ep.ln_mr) {
-        // folded LayerNorm: the tile's per-row (mean, rstd) and per-column sums go straight to LDS beyond the main loop's
-        // buffers (buffer_load ... lds, like the operand tiles): no VGPRs, no wait here - the main loop's first vmcnt wait +
-        // barrier covers them.  Rows / columns past the matrix read as zeros (num_records).
+    if (B16 && (g.ep.ln_mr || g.ep.ln_in)) {
+        // folded LayerNorm: the tile's per-row (mean, rstd) - or the producer's (sum, sumsq) partials they are made of - and
+        // per-column sums go straight to LDS beyond the main loop's buffers (buffer_load ... lds, like the operand tiles):
+        // no VGPRs, no wait here - the main loop's first vmcnt wait + barrier covers them.  Rows / columns past the matrix
+        // read as zeros (num_records).
         extern __shared__ __attribute__((aligned(16))) unsigned char slds0[];
         const int wb = __builtin_amdgcn_readfirstlane(wid) * 256;                  // this wave's 64 dwords
-        const __amdgpu_buffer_rsrc_t r_mr = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_mr + m0), 0, min(g.M - m0, SBM) * 8, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_mr, (lds_ptr_t)(slds0 + S_LDS + S_LDS_STATS + wb), 4, wb + lane * 4, 0, 0, 0);
+        const int rows_b = min(g.M - m0, SBM) * 8;
+        if (g.ep.ln_mr) {
+            const __amdgpu_buffer_rsrc_t r_mr = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_mr + m0), 0, rows_b, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_mr, (lds_ptr_t)(slds0 + S_LDS + S_LDS_STATS + wb), 4, wb + lane * 4, 0, 0, 0);
+        } else {
+            // (the partials wait in the region this tile's own output statistics use later, after they have been consumed)
+            for (int p = 0; p < g.ep.ln_parts; ++p) {
+                const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_in + (size_t)p * g.ep.ln_in_ld + m0), 0, rows_b, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_ptr_t)(slds0 + S_LDS + p * 2048 + wb), 4, wb + lane * 4, 0, 0, 0);
+            }
+        }
         if (wid < 4) {
             const __amdgpu_buffer_rsrc_t r_lc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ep.ln_c + n0), 0, min(g.N - n0, SBN) * 4, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_lc, (lds_ptr_t)(slds0 + S_LDS + S_LDS_STATS + 256 * 8 + wb), 4, wb + lane * 4, 0, 0, 0);
@@ -461,7 +471,19 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
     float* stage = reinterpret_cast<float*>(slds) + wid * 64 * ua::EP_LD;
     float2* part = g.ep.stats ? reinterpret_cast<float2*>(slds + S_LDS) + wid * 128 : nullptr;     // block-uniform
-    const bool fold = B16 && g.ep.ln_mr != nullptr;                                                // block-uniform
+    const bool fold = B16 && (g.ep.ln_mr != nullptr || g.ep.ln_in != nullptr);                     // block-uniform
+    if (B16 && g.ep.ln_in) {
+        // (mean, rstd) of the tile's rows from the producer's partials: ua_row_stats_finalize's arithmetic, tiles in index order
+        if (tid < SBM) {
+            const float2* pin = reinterpret_cast<const float2*>(slds + S_LDS) + tid;
+            double sm = 0.0, sq = 0.0;
+            for (int p = 0; p < g.ep.ln_parts; ++p) { const float2 v = pin[p * 256]; sm += (double)v.x; sq += (double)v.y; }
+            const double mean = sm * g.ep.ln_inv_n;
+            const double var = fmax(sq * g.ep.ln_inv_n - mean * mean, 0.0);
+            reinterpret_cast<float2*>(slds + S_LDS + S_LDS_STATS)[tid] = make_float2((float)mean, (float)(1.0 / sqrt(var + g.ep.ln_eps)));
+        }
+        __syncthreads();
+    }
     const float2* s_mr = reinterpret_cast<const float2*>(slds + S_LDS + S_LDS_STATS) + wm * 128;
     const float* s_lc = reinterpret_cast<const float*>(slds + S_LDS + S_LDS_STATS + 256 * 8) + wn * 64;
 #ifdef UA_SPLIT_TRACE
@@ -594,8 +616,8 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
 #ifdef UA_SPLIT_TRACE
     g.trace = g_trace; g.timeline = g_timeline;
 #endif
-    if (g.ep.ln_mr && sched != 16) return UA_EUNSUPPORTED;            // (the A/B schedules have no folded-LayerNorm staging)
-    const size_t lds = (size_t)S_LDS + (g.ep.stats || g.ep.ln_mr ? S_LDS_STATS + S_LDS_FOLD : 0);   // 139,264 B (+ 11,264)
+    if ((g.ep.ln_mr || g.ep.ln_in) && sched != 16) return UA_EUNSUPPORTED;            // (the A/B schedules have no folded-LayerNorm staging)
+    const size_t lds = (size_t)S_LDS + (g.ep.stats || g.ep.ln_mr || g.ep.ln_in ? S_LDS_STATS + S_LDS_FOLD : 0);   // 139,264 B (+ 11,264)
     static bool attr_set = false;
     if (!attr_set) {
         const int lds_max = S_LDS + S_LDS_STATS + S_LDS_FOLD;

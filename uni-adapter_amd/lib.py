@@ -29,7 +29,8 @@ class GemmEpilogue(C.Structure):
                 ('residual', _p), ('ldr', _i64),
                 ('pool_out', _p), ('ldp', _i64), ('pool_rows', _i32),
                 ('split_out', _p), ('ld_split', _i64), ('split_scale', _f),
-                ('row_stats_out', _p), ('ld_stats', _i64), ('ln_mean_rstd', _p), ('ln_colsum', _p)]
+                ('row_stats_out', _p), ('ld_stats', _i64), ('ln_mean_rstd', _p), ('ln_colsum', _p),
+                ('ln_stats_in', _p), ('ln_stats_ld', _i64), ('ln_parts', _i32), ('ln_n', _i32), ('ln_eps', _f)]
 
 
 class TtaState(C.Structure):

@@ -83,7 +83,8 @@ def _act_scale(bound):
 
 def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgroup_add=None, ldg=0,
           group_rows=0, act=0, residual=None, ldr=0, pool_out=None, ldp=0, pool_rows=0, alg_flops=None,
-          split_out=None, ld_split=0, split_scale=1.0, a_scale=None, stats_out=None, ln_mr=None, ln_colsum=None):
+          split_out=None, ld_split=0, split_scale=1.0, a_scale=None, stats_out=None, ln_mr=None, ln_colsum=None,
+          ln_stats=None, ln_n=0, ln_eps=0.0):
     """C (M,N) = A (M,K) @ W (N,K)^T + epilogue; all tensors already on device.
     W is an fp32 tensor (exact-f32 MFMA kernel, A fp32) or a SplitW (3xf16-split MFMA kernel, A an
     H32L32 split matrix with scale `a_scale`).  `split_out`: also/only emit the output in split form.
@@ -102,8 +103,11 @@ def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgr
     e.ldp, e.pool_rows = ldp, pool_rows
     if stats_out is not None:                      # (parts, rows, 2) partial row statistics of the output
         e.row_stats_out, e.ld_stats = stats_out.data_ptr(), stats_out.shape[1]
-    if ln_mr is not None:                          # folded LayerNorm on the A side
+    if ln_mr is not None:                          # folded LayerNorm on the A side: final (mean, rstd) per row ...
         e.ln_mean_rstd, e.ln_colsum = ln_mr.data_ptr(), ln_colsum.data_ptr()
+    elif ln_stats is not None:                     # ... or the producer's partials (at most 4 tiles), reduced by the consumer
+        e.ln_stats_in, e.ln_stats_ld, e.ln_parts, e.ln_n, e.ln_eps = ln_stats.data_ptr(), ln_stats.shape[1], ln_stats.shape[0], ln_n, ln_eps
+        e.ln_colsum = ln_colsum.data_ptr()
     prof = PROFILER
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -394,6 +398,9 @@ class PointcloudEncoder(nn.Module):
             # (sum, sumsq) partials; the consuming GEMM multiplies the un-normalised rows by gamma (.) W and applies mean / rstd
             # in its epilogue (include/uniadapter.h, ua_gemm_epilogue), so no LayerNorm pass over HBM is left.
             fq = b.f_qkv if fold else None
+            # statistics of x: up to 4 column tiles are reduced by the consuming GEMM itself, more by ua_row_stats_finalize
+            x_parts = (Cd + 255) // 256
+            xstat = dict(ln_stats=w['st_x'], ln_n=Cd, ln_eps=self.ln_eps) if fold and x_parts <= 4 else dict(ln_mr=w.get('mr_x'))
             if fq is None:
                 s1 = b.ln1_scale if sp else None
                 _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)
@@ -411,7 +418,7 @@ class PointcloudEncoder(nn.Module):
                           split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0)
                 else:
                     _gemm(w['xs'], Cd, fq[0], None, 3 * Cd, rows, 3 * Cd, Cd, bias=fq[1], a_scale=X_SPLIT_SCALE,
-                          split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0, ln_mr=w['mr_x'], ln_colsum=fq[2])
+                          split_out=w['qkv'], ld_split=3 * Cd, split_scale=1.0, ln_colsum=fq[2], **xstat)
                 if b.an_w is None:
                     lib.call('ua_attention_split', w['qkv'].data_ptr(), 3 * Cd, 1.0, None, 0, w['h'].data_ptr(), Cd, 1.0,
                              Bc, G, Hh, Cd // Hh, st)
@@ -427,28 +434,29 @@ class PointcloudEncoder(nn.Module):
             if fold:
                 _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att,
                       split_out=w['xs'], ld_split=Cd, split_scale=X_SPLIT_SCALE, stats_out=w['st_x'])
-                _row_stats(w['st_x'], (Cd + 255) // 256, rows, Cd, self.ln_eps, w['mr_x'])
+                if x_parts > 4:
+                    _row_stats(w['st_x'], x_parts, rows, Cd, self.ln_eps, w['mr_x'])
                 n1 = 2 * Hp if b.act == ACT_SWIGLU else Hp
                 fl1 = (4.0 if b.act == ACT_SWIGLU else 2.0) * rows * b.H * Cd
                 f2 = b.f_w2
                 if f2 is not None:
                     # the hidden activation leaves the fc1 GEMM un-normalised, in split form, with its row statistics
                     _gemm(w['xs'], Cd, b.f_w1[0], None, ld_h, rows, n1, Cd, bias=b.f_w1[1], act=b.act, alg_flops=fl1, a_scale=X_SPLIT_SCALE,
-                          ln_mr=w['mr_x'], ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale,
-                          stats_out=w['st_h'])
+                          ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale,
+                          stats_out=w['st_h'], **xstat)
                     _row_stats(w['st_h'], (n1 + 255) // 256, rows, b.H, self.ln_eps, w['mr_h'])
                     w2, b2, kw = f2[0], f2[1], dict(ln_mr=w['mr_h'], ln_colsum=f2[2])
                 else:
                     _gemm(w['xs'], Cd, b.f_w1[0], None, ld_h, rows, n1, Cd, bias=b.f_w1[1], act=b.act, alg_flops=fl1, a_scale=X_SPLIT_SCALE,
-                          ln_mr=w['mr_x'], ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale)
+                          ln_colsum=b.f_w1[2], split_out=w['hidn'], ld_split=ld_h, split_scale=b.hraw_scale, **xstat)
                     w2, b2, kw = b.w2, b.b2, {}
                 last = bi == nb - 1 or self.blocks[bi + 1].f_qkv is None      # the next block runs its own norm1 kernel on x
                 if not last:
                     kw.update(split_out=w['xs'], ld_split=Cd, split_scale=X_SPLIT_SCALE, stats_out=w['st_x'])
                 _gemm(w['hidn'], ld_h, w2, x, Cd, rows, Cd, Hp, bias=b2, scale=b.gamma2, residual=x, ldr=Cd,
                       alg_flops=2.0 * rows * Cd * b.H, a_scale=b.hraw_scale, **kw)
-                if not last:
-                    _row_stats(w['st_x'], (Cd + 255) // 256, rows, Cd, self.ln_eps, w['mr_x'])
+                if not last and x_parts > 4:
+                    _row_stats(w['st_x'], x_parts, rows, Cd, self.ln_eps, w['mr_x'])
                 continue
             _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att)
             s2 = b.ln2_scale if sp else None
