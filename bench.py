@@ -81,7 +81,7 @@ def host_cores():
     return max(1, min(n, cap))
 
 
-PMC_FILES = ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json', 'r02_pmc.json')     # oldest first: later files win
+PMC_FILES = ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json', 'r02_pmc.json', 'r02b_pmc.json')     # oldest first: later files win
 
 
 def _pmc_table():
@@ -397,7 +397,7 @@ def main():
                     'mfma_dtype': 'f32'}
         # `traffic` stays null: the launches of a step have 7 different shapes; the PMC passes were taken on the
         # qkv shape (16416 x 3072 x 1024) alone and are attached as `pmc_probe`
-        roof['pmc_probe'] = pmc_probe('gemm_split_kernel<16>' if dom == 'split' else 'gemm_f32_mfma_kernel')
+        roof['pmc_probe'] = (pmc_probe('gemm_split_kernel<16, 3>') or pmc_probe('gemm_split_kernel<16>')) if dom == 'split' else pmc_probe('gemm_f32_mfma_kernel')
         roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),
                      'kernel_share_of_step_time': round(g['ms'] * 1e-3 / dt / world, 4)})
