@@ -331,10 +331,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(precision, want_feats=0):
+    def run_mode(precision, want_feats=0, fold_layernorm=None):
         """W warm-up + K timed steps of the full loop in one GEMM mode; returns the result fields."""
         model = PE.create_uni3d_from_state_dict(sd, num_group=cfg['G'], group_size=cfg['S'], num_heads=cfg['heads'], device=dev,
-                                                precision=precision)
+                                                precision=precision, fold_layernorm=fold_layernorm)
         eng = TtaEngine(model, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, cfg['M'], res_learning=cfg['res'],
                         chunk=n_global, device=dev, overlap=a.overlap)
 
@@ -441,6 +441,14 @@ def main():
                                    'one GPU: encoder on the main stream, in-order cache replay on a second stream')},
         'roofline': res['roofline'],
     }
+    if world == 1 and main_mode == 'split' and a.both_modes and 'includes' in res['roofline']:
+        # the same stream with the LayerNorms as separate kernels (UA_FOLD_LN=0): the GEMM launches then do GEMM work only,
+        # which is the like-for-like figure against round 1's roofline.frac; the step itself is slower
+        r0, _ = run_mode(main_mode, fold_layernorm=False)
+        out['roofline']['without_folded_layernorm'] = {
+            'value': r0['value'], 'ms_per_step': r0['ms_per_step'], 'achieved': r0['roofline']['achieved'], 'frac': r0['roofline']['frac'],
+            'executed_frac': r0['roofline']['executed_frac'], 'ms_per_launch_avg': r0['roofline']['ms_per_launch_avg'],
+            'note': 'same bench, same process, LayerNorm kernels instead of the fold: faster GEMM launches, slower step'}
     other, res2 = None, None
     if a.both_modes:
         other = 'f32' if main_mode == 'split' else 'split'
