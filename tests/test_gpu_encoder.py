@@ -90,6 +90,30 @@ def test_split_mode_tracks_f32_mode_full_depth():
     assert dl < 1e-3
 
 
+def test_folded_layernorms_track_the_layernorm_kernels_full_depth():
+    """24-block Uni3D-L in split mode: LayerNorms folded into the GEMMs (default) vs run as kernels (fold_layernorm=False), and each
+    against the exact-f32 mode.  The fold is an algebraic re-association: the features must agree at fp32
+    round-off level, and the folded path must be no further from the exact-f32 mode than 3x the un-folded one."""
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd import synthetic
+    sd = synthetic.uni3d_state_dict(0, depth=24, device='cuda')
+    pc = _clouds(5, 1024, 17).cuda()                                 # 5 clouds: a ragged last row panel in every GEMM
+    text = synthetic.text_bank(40, 1024, 0, device='cuda')
+    outs = {}
+    for name, kw in (('f32', dict(precision='f32')), ('fold', dict(precision='split', fold_layernorm=True)),
+                     ('kernels', dict(precision='split', fold_layernorm=False))):
+        m = create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16, **kw)
+        assert m.point_encoder.fold_ln == (name == 'fold')
+        outs[name] = torch.nn.functional.normalize(m.encode_pc(pc).double(), dim=1)
+        del m
+    logit = lambda a, b: (100.0 * (outs[a] - outs[b]) @ text.double().T).abs().max().item()
+    d_fk, d_f32_fold, d_f32_k = logit('fold', 'kernels'), logit('f32', 'fold'), logit('f32', 'kernels')
+    print('max |d logit|: fold vs kernels', d_fk, '| f32 vs fold', d_f32_fold, '| f32 vs kernels', d_f32_k)
+    assert (1 - (outs['fold'] * outs['kernels']).sum(1)).max().item() < 1e-10
+    assert d_fk < 1e-3 and d_f32_fold < 1e-3
+    assert d_f32_fold <= 3.0 * d_f32_k + 1e-5
+
+
 # ---------------------------------------------------------------- ULIP-2 PointBERT variant (section 8 A4b)
 def _golden(name):
     import os
