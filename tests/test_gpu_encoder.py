@@ -105,6 +105,8 @@ def test_folded_layernorms_track_the_layernorm_kernels_full_depth():
         m = create_uni3d_from_state_dict(sd, num_group=512, group_size=64, num_heads=16, **kw)
         assert m.point_encoder.fold_ln == (name == 'fold')
         outs[name] = torch.nn.functional.normalize(m.encode_pc(pc).double(), dim=1)
+        if name == 'fold':                                           # the one-time check of the row statistics ran and found benign rows
+            assert m.point_encoder._fold_checked and 0.0 <= m.point_encoder.fold_mean2_over_var < 100.0, m.point_encoder.fold_mean2_over_var
         del m
     logit = lambda a, b: (100.0 * (outs[a] - outs[b]) @ text.double().T).abs().max().item()
     d_fk, d_f32_fold, d_f32_k = logit('fold', 'kernels'), logit('f32', 'fold'), logit('f32', 'kernels')

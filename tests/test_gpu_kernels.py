@@ -976,6 +976,58 @@ def test_gemm_split_folded_layernorm_from_the_producers_partials(ua, parts):
         ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
 
 
+def test_folded_layernorm_with_outlier_channels_and_offset_rows(ua):
+    """Producer statistics -> consumer fold on hard rows: a 'massive activation' channel (300x), rows whose mean is 10x their
+    standard deviation (the one-pass variance E[x^2] - mean^2 loses log10(1 + mean^2/var) digits), a near-constant row.
+    End to end through ua_gemm_split twice (statistics written by the first launch's epilogue, folded LayerNorm in the second)."""
+    from uni_adapter_amd.lib import GemmEpilogue
+    g = torch.Generator().manual_seed(99)
+    M, K0, Cd, N = 640, 64, 1024, 512
+    # first launch: x = A0 @ W0^T + residual  (residual carries the structure we want in x)
+    A0 = torch.randn(M, K0, generator=g) * 0.1; W0 = torch.randn(Cd, K0, generator=g) * 0.1
+    res = torch.randn(M, Cd, generator=g)
+    res[:, 7] *= 300.0                                      # outlier channel
+    res[100:200] += 10.0                                    # mean = 10 sigma
+    res[300] = 5.0 + 1e-3 * torch.randn(Cd, generator=g)     # near-constant row
+    x_ref = A0.double() @ W0.double().T + res.double()
+    gamma = 1 + 0.2 * torch.randn(Cd, generator=g); gamma[7] = 0.01; beta = 0.1 * torch.randn(Cd, generator=g)
+    W1 = torch.randn(N, Cd, generator=g) / 32; b1 = torch.randn(N, generator=g)
+    ref = torch.nn.functional.layer_norm(x_ref, (Cd,), gamma.double(), beta.double(), 1e-6) @ W1.double().T + b1.double()
+    A0s, W0s = _split(ua, dev(A0)), _split(ua, dev(W0), scale=1024.0)
+    e = GemmEpilogue(); keep = [dev(res)]
+    e.residual = keep[0].data_ptr(); e.ldr = Cd
+    xs = torch.zeros(M, Cd, device='cuda'); e.split_out = xs.data_ptr(); e.ld_split = Cd; e.split_scale = 1.0
+    st = torch.zeros(4, M, 2, device='cuda'); e.row_stats_out = st.data_ptr(); e.ld_stats = M
+    x = torch.zeros(M, Cd, device='cuda')
+    ua.call('ua_gemm_split', A0s.data_ptr(), K0, 1.0, W0s.data_ptr(), K0, 1024.0, ua.ptr(x), Cd, M, Cd, K0, C.byref(e), ua.stream_ptr())
+    Wf = W1 * gamma
+    ws = min(4096.0, 2.0 ** math.floor(math.log2(30000.0 / Wf.abs().max().item())))
+    hi = (Wf * ws).half(); lo = (Wf * ws - hi.float()).half()
+    colsum = ((hi.double() + lo.double()) / ws).sum(1).float()
+    bias = (b1.double() + W1.double() @ beta.double()).float()
+    Wfs = _split(ua, dev(Wf), Cd, ws)
+    e2 = GemmEpilogue(); keep2 = [dev(bias), dev(colsum)]
+    e2.bias, e2.ln_colsum = keep2[0].data_ptr(), keep2[1].data_ptr()
+    e2.ln_stats_in = st.data_ptr(); e2.ln_stats_ld = M; e2.ln_parts = 4; e2.ln_n = Cd; e2.ln_eps = 1e-6
+    out = torch.zeros(M, N, device='cuda')
+    ua.call('ua_gemm_split', xs.data_ptr(), Cd, 1.0, Wfs.data_ptr(), Cd, ws, ua.ptr(out), N, M, N, Cd, C.byref(e2), ua.stream_ptr())
+    # the un-folded pipeline on the same x
+    y = torch.empty(M, Cd, device='cuda')
+    ua.call('ua_layernorm_split', ua.ptr(x), Cd, ua.ptr(dev(gamma)), ua.ptr(dev(beta)), 1e-6, y.data_ptr(), Cd, M, Cd, Cd, 8.0, ua.stream_ptr())
+    W1s = _split(ua, dev(W1), Cd, ws)
+    e3 = GemmEpilogue(); keep3 = [dev(b1)]; e3.bias = keep3[0].data_ptr()
+    out0 = torch.zeros(M, N, device='cuda')
+    ua.call('ua_gemm_split', y.data_ptr(), Cd, 8.0, W1s.data_ptr(), Cd, ws, ua.ptr(out0), N, M, N, Cd, C.byref(e3), ua.stream_ptr())
+    err = (out.cpu().double() - ref).abs(); err0 = (out0.cpu().double() - ref).abs()
+    rows = {'plain': [i for i in range(M) if not (100 <= i < 200) and i != 300], 'mean = 10 sigma': list(range(100, 200)), 'near-constant': [300]}
+    for name, idx in rows.items():
+        print(f'{name:16s} folded max {err[idx].max():.3e} | LN kernel + GEMM max {err0[idx].max():.3e} | |ref| max {ref[idx].abs().max():.2f}')
+    assert err[rows['plain']].max().item() <= 3.0 * err0[rows['plain']].max().item() + 1e-6
+    assert err[rows['mean = 10 sigma']].max().item() <= 2e-4            # (1 + mean^2/var) = 101 x the fp32 statistics' round-off
+    # near-constant row: var = 1e-6, mean^2/var = 2.5e7 - the one-pass variance has no digits left; the result stays finite
+    assert torch.isfinite(out).all()
+
+
 def test_gemm_f32_rejects_the_folded_layernorm(ua):
     from uni_adapter_amd.lib import GemmEpilogue
     x = torch.zeros(64, 64, device='cuda'); e = GemmEpilogue(); e.row_stats_out = x.data_ptr(); e.ld_stats = 64

@@ -13,6 +13,7 @@ row Bc*G+b, so every big GEMM sees Bc*G (a multiple of 128) rows plus one thin t
 import ctypes as C
 import math
 import os
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -172,6 +173,7 @@ class PointcloudEncoder(nn.Module):
         if fold_layernorm is None:
             fold_layernorm = os.environ.get('UA_FOLD_LN', '1') != '0'
         self.fold_ln = bool(fold_layernorm) and sp
+        self._fold_checked = False
         if self.group_size not in (32, 64):
             raise NotImplementedError('patch-embed max-pool epilogue is built for group sizes 64 (Uni3D) and 32 (PointBERT)')
         if variant not in ('uni3d', 'ulip', 'openshape'):
@@ -376,6 +378,26 @@ class PointcloudEncoder(nn.Module):
                   mr_x=e(rows, 2), mr_h=e(rows, 2))
 
     @torch.no_grad()
+    def _fold_check(self, w, rows, Cd):
+        """Once per encoder: the one-pass row statistics of the folded LayerNorms (sum, sum of squares in fp32 partials) lose
+        log10(1 + mean^2/var) digits.  Look at the last block's statistics of the first forward and say so if any token row has
+        |mean| > 10 sigma (measured there: 7x the LayerNorm kernel's error, still 5e-6 relative)."""
+        self._fold_checked = True
+        worst = 0.0
+        for key, n in (('st_x', Cd), ('st_h', self.blocks[-1].H)):
+            st = w.get(key)
+            if st is None or (key == 'st_h' and self.blocks[-1].f_w2 is None):    # (no sub-LN: no hidden statistics were written)
+                continue
+            parts = (Cd + 255) // 256 if key == 'st_x' else ((2 if self.blocks[-1].act == ACT_SWIGLU else 1) * self.blocks[-1].Hp + 255) // 256
+            tot = st[:parts, :rows].double().sum(0)
+            mean = tot[:, 0] / n
+            var = (tot[:, 1] / n - mean * mean).clamp_min(1e-30)
+            worst = max(worst, float((mean * mean / var).max()))
+        self.fold_mean2_over_var = worst
+        if worst > 100.0:
+            warnings.warn(f'folded LayerNorm: a token row has mean^2/var = {worst:.3g} (> 100); its one-pass statistics keep '
+                          f'{7.2 - math.log10(1 + worst):.1f} of 7.2 digits - consider fold_layernorm=False / UA_FOLD_LN=0')
+
     def _run_blocks(self, w, Bc):
         """The transformer blocks on the token rows of w['x'] (in place); returns w['x']."""
         G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
@@ -474,6 +496,8 @@ class PointcloudEncoder(nn.Module):
                 lib.call('ua_split_f16', hid.data_ptr(), ld_h, w['hidn'].data_ptr(), ld_h, rows, b.H, Hp, 1.0, st)
                 hid, s_h = w['hidn'], 1.0
             _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H, a_scale=s_h)
+        if self.fold_ln and not self._fold_checked and self.blocks:
+            self._fold_check(w, rows, Cd)
         return x
 
     @torch.no_grad()
