@@ -315,7 +315,8 @@ int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
 /* Same attention with fp32-accurate products on the f16 matrix cores: qkv is an H32L32 split matrix
  * (rows, 3*H*hd) with scale qkv_scale (as emitted by ua_gemm_split's split_out), the result is
  * written as fp32 (out, optional) and/or as an H32L32 split matrix (out_split, optional) for the
- * proj GEMM.  Softmax statistics and all accumulation are fp32.                                   */
+ * proj GEMM.  Softmax statistics and all accumulation are fp32.  G % 128 == 0, G <= 1024 (the CLS
+ * query's one-query path keeps the G + 1 scores of a (cloud, head) pair in LDS).                  */
 int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
                        void* out_split, int64_t ldos, float out_scale,
                        int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
