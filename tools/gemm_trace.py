@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--shapes', default='qkv,proj,fc1,fc2,conv3,small')
     ap.add_argument('--build-only', action='store_true')
+    ap.add_argument('--clouds', type=int, default=31, help='token rows = clouds * 513 (the bench step encodes 62 clouds)')
     ap.add_argument('--store-only', action='store_true', help='ablation: first epilogue half = 16 plain float4 row stores (no LDS, no math)')
     ap.add_argument('--pool-only', action='store_true', help='no C stores: epilogue writes only a 64-row max-pool (store-path ablation)')
     a = ap.parse_args()
@@ -49,6 +50,8 @@ def main():
     dev = torch.device('cuda')
     for name in a.shapes.split(','):
         M, N, K = SHAPES[name]
+        if a.clouds != 31 and M == 15903:
+            M = a.clouds * 513
         A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / K ** 0.5
         As = torch.empty(M, K, device=dev); Ws = torch.empty(N, K, device=dev)        # H32L32 images (4 B / column)
         for x, y, r, sc in ((A, As, M, 1.0), (W, Ws, N, 256.0)):
@@ -115,6 +118,10 @@ def main():
           clk = (T[fullm, 9] / (T[fullm, 1] - T[fullm, 0])).median().item() * 0.1       # cycles per 10 ns -> GHz
           print(f'    schedule {sched}: full tiles main loop {ml[fullm].mean():.1f} us, epilogue {ep[fullm].mean():.1f} us, in-kernel clock {clk:.2f} GHz, '
                 f'{T[fullm, 9].mean() / (K // 32):.0f} cycles per K-tile', flush=True)
+          span_s = (T[:, 2].max() - T[:, 0].min()) / 100
+          busy_s = ((T[:, 2] - T[:, 0]) / 100).sum() / 256
+          print(f'      kernel span {span_s:.1f} us; sum(block time)/256 CUs = {busy_s:.1f} us -> {span_s - busy_s:.1f} us per CU not inside a block '
+                f'(dispatch gaps, round quantisation, tail); {nt} tiles = {nt / 256:.2f} rounds', flush=True)
           F = T[fullm]
           seg = [(F[:, 4] - F[:, 1]), (F[:, 5] - F[:, 4]), (F[:, 6] - F[:, 5]), (F[:, 7] - F[:, 6]), (F[:, 8] - F[:, 7]), (F[:, 2] - F[:, 8])]
           print('      wave 0 epilogue (us): stage0 %.2f | rows0 %.2f | stage1 %.2f | rows1 %.2f | store drain %.2f | barrier %.2f' % tuple(float(x.mean()) / 100 for x in seg), flush=True)
