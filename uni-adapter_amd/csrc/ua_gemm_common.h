@@ -131,6 +131,7 @@ struct EpiArgs {
     // LayerNorm folded around the GEMM (split kernel only; see ua_gemm_epilogue in include/uniadapter.h)
     float2* stats; long long ld_stats;             // out: per (column tile, row) partial (sum, sum of squares) of the output values
     const float2* ln_mr; const float* ln_c;        // in: per-row (mean, rstd) of A's rows and the row sums of W: v = rstd*(acc - mean*ln_c[n]) + bias[n]
+    int lean_ok;                                   // the compile-time-specialised row loops may be used (UA_EPI_LEAN=0: A/B aid)
     const float2* ln_in; long long ln_in_ld; int ln_parts; double ln_inv_n, ln_eps;   // in (instead of ln_mr): the producer's partials, reduced by the consumer
 };
 
@@ -196,11 +197,20 @@ __device__ __forceinline__ void stage_64x64_b16_fold(float* stage, const f32x4 (
 // FULL: the sub-tile lies entirely inside the matrix - no per-lane row / column guards.  ACT is a
 // template parameter so the activation switch is outside the row loop; the optional operands are
 // wave-uniform (scalar) branches and all row addresses advance by pointer increments.
-template <bool FULL, int ACT>
+// LEAN != 0: a transformer-block launch whose optional operands are known at compile time (bit 0 fp32 output, bit 1 split
+// output, bit 2 residual, bit 3 row statistics; no BN affine, row-group addend, per-row scale or pooling): the row loop is
+// VALU-issue-bound (~80-110 instructions per iteration in the generic form, 32 iterations per wave), so the wave-uniform
+// flag tests and the pooling maxima it never stores are compiled out.  Same arithmetic, same bytes.
+template <bool FULL, int ACT, int LEAN = 0>
 __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base, float2* part, bool prescaled) {
     // the library is built with -ffp-contract=off for the element-wise cache kernels; here acc*scale + bias and the BN
     // affine may fuse (one rounding instead of two, half the VALU instructions of the row loop)
 #pragma clang fp contract(fast)
+    constexpr bool lean = LEAN != 0;
+    const bool have_res = lean ? (LEAN & 4) != 0 : g.residual != nullptr;
+    const bool have_rga = lean ? false : g.rga != nullptr;
+    const bool have_rs = lean ? false : g.row_scale != nullptr;
+    const bool have_pool = lean ? false : g.pool != nullptr;
     constexpr bool swiglu = ACT == 3;
     constexpr bool lse = ACT == 4;
     const int lr = lane >> 4, c4 = (lane & 15) * 4;
@@ -222,14 +232,14 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     };
     const float as = prescaled ? 1.0f : g.acc_scale;               // (folded LayerNorm: the staging step applied acc_scale * rstd already)
     const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
-    const float4 s4 = ld4(g.scale, ncol0, g.N, 1.f);                 // v = (acc*as + bias + rga) * scale + shift
-    const float4 t4 = ld4(g.shift, ncol0, g.N, 0.f);
+    const float4 s4 = ld4(lean ? nullptr : g.scale, ncol0, g.N, 1.f);                 // v = (acc*as + bias + rga) * scale + shift
+    const float4 t4 = ld4(lean ? nullptr : g.shift, ncol0, g.N, 0.f);
     // Every global LOAD of the sub-tile is issued here, before the first store: vmcnt counts loads and
     // stores in one in-order counter, so a load inside the store loop would make each iteration wait
     // for the previous iteration's store to be acknowledged.
     // row-group addend (group_rows is a multiple of 32): one vector for rows 0..31, one for rows 32..63
     float4 ba = b4, bb = b4;
-    if (g.rga) {
+    if (have_rga) {
         if (FULL || mbase < g.M) {
             const float4 a = ld4(g.rga + (size_t)(mbase / g.group_rows) * g.ldg, ncol0, g.N, 0.f);
             ba.x += a.x; ba.y += a.y; ba.z += a.z; ba.w += a.w;
@@ -243,7 +253,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     float4 res[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) res[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.residual && active) {
+    if (have_res && active) {
         const float* rp = g.residual + (size_t)m_first * g.ldr;            // ld4 adds the column
         const size_t rstep = (size_t)4 * g.ldr;
 #pragma unroll
@@ -253,19 +263,19 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     float rs[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) rs[p] = 1.f;
-    if (g.row_scale) {
+    if (have_rs) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
             if (FULL || m_first + p * 4 < g.M) rs[p] = g.row_scale[m_first + p * 4];
     }
-    const bool have_stats = part != nullptr;                         // wave-uniform
-    const bool affine = g.scale || g.shift;
+    const bool have_stats = lean ? (LEAN & 8) != 0 : part != nullptr;    // wave-uniform
+    const bool affine = lean ? false : (g.scale || g.shift);
     float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
     const bool pool32 = g.pool_rows == 32;
     const float* sp = stage + lr * EP_LD + c4;
     // wave-uniform flags stay scalar: testing the per-lane pointers instead makes every `if` an exec-mask branch
-    const bool have_c = g.C != nullptr, have_s = g.Cs != nullptr;
+    const bool have_c = lean ? (LEAN & 1) != 0 : g.C != nullptr, have_s = lean ? (LEAN & 2) != 0 : g.Cs != nullptr;
     float* cp = g.C + (size_t)m_first * g.ldc + nout0;
     unsigned char* qp = g.Cs + (size_t)m_first * g.ldcs * 4 + split_col_off(nout0);
     const size_t cstep = (size_t)4 * g.ldc, qstep = (size_t)16 * g.ldcs;
@@ -334,12 +344,12 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
                 *reinterpret_cast<f16x4*>(qp + p * qstep + 64) = lo;
             }
         }
-        if (lane_ok) {
+        if ((lean ? false : true) && lane_ok) {
             if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
             else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
         }
     }
-    if (g.pool) {                                                    // max over this wave's 64 rows
+    if (have_pool) {                                                 // max over this wave's 64 rows
 #pragma unroll
         for (int o = 16; o <= 32; o <<= 1) {
             pm.x = fmaxf(pm.x, __shfl_xor(pm.x, o)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, o));
@@ -376,14 +386,30 @@ __device__ __forceinline__ void epilogue_64x64_act(const EpiArgs& g, const float
 // part: LDS slots of this wave's 64 rows for the row statistics (stats output requested), else nullptr
 __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* stage, int lane, int mbase, int ncol_base, float2* part = nullptr,
                                                bool prescaled = false) {
-    if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base, part, prescaled);   // wave-uniform
-    else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base, part, prescaled);
+    if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) {                                                    // wave-uniform
+        // the transformer blocks' launches (point_encoder.py: qkv | fc1 | proj, fc2 with and without the folded LayerNorm's outputs)
+        if (g.lean_ok && !g.scale && !g.shift && !g.rga && !g.row_scale && !g.pool && (g.act == 0 || g.act == 3)) {
+            const int code = (g.C ? 1 : 0) | (g.Cs ? 2 : 0) | (g.residual ? 4 : 0) | (part ? 8 : 0);
+            if (g.act == 0) {
+                if (code == 2)  { epilogue_64x64_impl<true, 0, 2>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+                if (code == 15) { epilogue_64x64_impl<true, 0, 15>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+                if (code == 5)  { epilogue_64x64_impl<true, 0, 5>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+            } else {
+                if (code == 10) { epilogue_64x64_impl<true, 3, 10>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+                if (code == 2)  { epilogue_64x64_impl<true, 3, 2>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+                if (code == 1)  { epilogue_64x64_impl<true, 3, 1>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+            }
+        }
+        epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base, part, prescaled);
+    } else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base, part, prescaled);
 }
 
 // Host-side validation + translation of the public epilogue descriptor (shared by both entry points).
 static inline int fill_epi(EpiArgs& e, const ua_gemm_epilogue* ep, int M, int N, float* C, long long ldc) {
     e = EpiArgs{};
     e.M = M; e.N = N; e.acc_scale = 1.0f; e.C = C; e.ldc = ldc;
+    static const int lean_ok = [] { const char* v = getenv("UA_EPI_LEAN"); return v ? atoi(v) : 1; }();
+    e.lean_ok = lean_ok;
     if (ep) {
         e.bias = ep->bias; e.scale = ep->scale; e.shift = ep->shift;
         e.rga = ep->rowgroup_add; e.ldg = ep->ldg; e.group_rows = ep->group_rows;
