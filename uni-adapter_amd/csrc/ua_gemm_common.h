@@ -197,8 +197,8 @@ __device__ __forceinline__ void stage_64x64_b16_fold(float* stage, const f32x4 (
 // FULL: the sub-tile lies entirely inside the matrix - no per-lane row / column guards.  ACT is a
 // template parameter so the activation switch is outside the row loop; the optional operands are
 // wave-uniform (scalar) branches and all row addresses advance by pointer increments.
-// LEAN != 0: a transformer-block launch whose optional operands are known at compile time (bit 0 fp32 output, bit 1 split
-// output, bit 2 residual, bit 3 row statistics; no BN affine, row-group addend, per-row scale or pooling): the row loop is
+// LEAN != 0: a launch whose optional operands are known at compile time (bit 0 fp32 output, bit 1 split output, bit 2 residual,
+// bit 3 row statistics, bit 4 64-row max-pool, bit 5 BN affine + row-group addend; never a per-row scale or a logsumexp): the row loop is
 // VALU-issue-bound (~80-110 instructions per iteration in the generic form, 32 iterations per wave), so the wave-uniform
 // flag tests and the pooling maxima it never stores are compiled out.  Same arithmetic, same bytes.
 template <bool FULL, int ACT, int LEAN = 0>
@@ -208,9 +208,9 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
 #pragma clang fp contract(fast)
     constexpr bool lean = LEAN != 0;
     const bool have_res = lean ? (LEAN & 4) != 0 : g.residual != nullptr;
-    const bool have_rga = lean ? false : g.rga != nullptr;
+    const bool have_rga = lean ? (LEAN & 32) != 0 : g.rga != nullptr;
     const bool have_rs = lean ? false : g.row_scale != nullptr;
-    const bool have_pool = lean ? false : g.pool != nullptr;
+    const bool have_pool = lean ? (LEAN & 16) != 0 : g.pool != nullptr;
     constexpr bool swiglu = ACT == 3;
     constexpr bool lse = ACT == 4;
     const int lr = lane >> 4, c4 = (lane & 15) * 4;
@@ -232,8 +232,8 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     };
     const float as = prescaled ? 1.0f : g.acc_scale;               // (folded LayerNorm: the staging step applied acc_scale * rstd already)
     const float4 b4 = ld4(g.bias, ncol0, g.N, 0.f);
-    const float4 s4 = ld4(lean ? nullptr : g.scale, ncol0, g.N, 1.f);                 // v = (acc*as + bias + rga) * scale + shift
-    const float4 t4 = ld4(lean ? nullptr : g.shift, ncol0, g.N, 0.f);
+    const float4 s4 = ld4(lean && !(LEAN & 32) ? nullptr : g.scale, ncol0, g.N, 1.f);   // v = (acc*as + bias + rga) * scale + shift
+    const float4 t4 = ld4(lean && !(LEAN & 32) ? nullptr : g.shift, ncol0, g.N, 0.f);
     // Every global LOAD of the sub-tile is issued here, before the first store: vmcnt counts loads and
     // stores in one in-order counter, so a load inside the store loop would make each iteration wait
     // for the previous iteration's store to be acknowledged.
@@ -269,10 +269,10 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
             if (FULL || m_first + p * 4 < g.M) rs[p] = g.row_scale[m_first + p * 4];
     }
     const bool have_stats = lean ? (LEAN & 8) != 0 : part != nullptr;    // wave-uniform
-    const bool affine = lean ? false : (g.scale || g.shift);
+    const bool affine = lean ? (LEAN & 32) != 0 : (g.scale || g.shift);
     float4 pm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);     // rows 0..63 (pool 64) / 0..31 (pool 32)
     float4 pm2 = pm;                                                          // rows 32..63 when pooling 32-row groups
-    const bool pool32 = g.pool_rows == 32;
+    const bool pool32 = lean ? false : g.pool_rows == 32;
     const float* sp = stage + lr * EP_LD + c4;
     // wave-uniform flags stay scalar: testing the per-lane pointers instead makes every `if` an exec-mask branch
     const bool have_c = lean ? (LEAN & 1) != 0 : g.C != nullptr, have_s = lean ? (LEAN & 2) != 0 : g.Cs != nullptr;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
                 *reinterpret_cast<f16x4*>(qp + p * qstep + 64) = lo;
             }
         }
-        if ((lean ? false : true) && lane_ok) {
+        if ((lean ? (LEAN & 16) != 0 : true) && lane_ok) {
             if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
             else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
         }
@@ -388,8 +388,8 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
                                                bool prescaled = false) {
     if (mbase + 64 <= g.M && ncol_base + 64 <= g.N) {                                                    // wave-uniform
         // the transformer blocks' launches (point_encoder.py: qkv | fc1 | proj, fc2 with and without the folded LayerNorm's outputs)
+        const int code = (g.C ? 1 : 0) | (g.Cs ? 2 : 0) | (g.residual ? 4 : 0) | (part ? 8 : 0);
         if (g.lean_ok && !g.scale && !g.shift && !g.rga && !g.row_scale && !g.pool && (g.act == 0 || g.act == 3)) {
-            const int code = (g.C ? 1 : 0) | (g.Cs ? 2 : 0) | (g.residual ? 4 : 0) | (part ? 8 : 0);
             if (g.act == 0) {
                 if (code == 2)  { epilogue_64x64_impl<true, 0, 2>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
                 if (code == 15) { epilogue_64x64_impl<true, 0, 15>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
@@ -399,6 +399,15 @@ __device__ __forceinline__ void epilogue_64x64(const EpiArgs& g, const float* st
                 if (code == 2)  { epilogue_64x64_impl<true, 3, 2>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
                 if (code == 1)  { epilogue_64x64_impl<true, 3, 1>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
             }
+        }
+        // the mini-PointNet's per-point convolutions (K = 128 .. 512: the epilogue is up to three quarters of a tile's time):
+        // conv2 = 64-row max-pool + split copy, conv3 = row-group addend + BN affine + ReLU -> split copy, conv4 = max-pool only
+        if (g.lean_ok == 1 && !g.row_scale && !g.residual && !part && !g.C) {
+            const bool aff = g.scale && g.shift && g.rga, none = !g.scale && !g.shift && !g.rga;
+            const bool pool64 = g.pool && g.pool_rows == 64;
+            if (g.act == 0 && none && pool64 && g.Cs)  { epilogue_64x64_impl<true, 0, 2 | 16>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+            if (g.act == 0 && none && pool64 && !g.Cs) { epilogue_64x64_impl<true, 0, 16>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
+            if (g.act == 1 && aff && !g.pool && g.Cs)  { epilogue_64x64_impl<true, 1, 2 | 32>(g, stage, lane, mbase, ncol_base, part, prescaled); return; }
         }
         epilogue_64x64_act<true>(g, stage, lane, mbase, ncol_base, part, prescaled);
     } else epilogue_64x64_act<false>(g, stage, lane, mbase, ncol_base, part, prescaled);
