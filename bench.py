@@ -448,7 +448,8 @@ def main():
         out['roofline']['without_folded_layernorm'] = {
             'value': r0['value'], 'ms_per_step': r0['ms_per_step'], 'achieved': r0['roofline']['achieved'], 'frac': r0['roofline']['frac'],
             'executed_frac': r0['roofline']['executed_frac'], 'ms_per_launch_avg': r0['roofline']['ms_per_launch_avg'],
-            'note': 'same bench, same process, LayerNorm kernels instead of the fold: faster GEMM launches, slower step'}
+            'note': 'same bench, same process, LayerNorm kernels instead of the fold: faster GEMM launches; ONE sequential leg, so its value is within the '
+                    'run-to-run spread (+-2 %) of the headline leg - the interleaved A/B (fold +2.8 % whole step) is profiles/r02b_layernorm_fold_ab_final_code.txt'}
     other, res2 = None, None
     if a.both_modes:
         other = 'f32' if main_mode == 'split' else 'split'
