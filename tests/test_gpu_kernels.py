@@ -1028,6 +1028,21 @@ def test_folded_layernorm_with_outlier_channels_and_offset_rows(ua):
     assert torch.isfinite(out).all()
 
 
+def test_specialised_epilogue_loops_write_the_same_bytes():
+    """The compile-time-specialised epilogue row loops (UA_EPI_LEAN=1, default) against the generic loop (=0) on every launch shape
+    that has one: bit-identical outputs, statistics and pooled maxima (two child processes: the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for v in ('1', '0'):
+        p = subprocess.run([sys.executable, os.path.join(root, 'tests', 'helpers', 'epilogue_digest.py')], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, UA_EPI_LEAN=v))
+        assert p.returncode == 0, p.stderr[-2000:]
+        digests.append([l for l in p.stdout.splitlines() if l.startswith('digest')][0])
+    assert digests[0] == digests[1]
+
+
 def test_gemm_f32_rejects_the_folded_layernorm(ua):
     from uni_adapter_amd.lib import GemmEpilogue
     x = torch.zeros(64, 64, device='cuda'); e = GemmEpilogue(); e.row_stats_out = x.data_ptr(); e.ld_stats = 64
