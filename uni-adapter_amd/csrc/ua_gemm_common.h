@@ -290,6 +290,40 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
         const float asr = as * rs[p];
         v.x = v.x * asr + bp.x; v.y = v.y * asr + bp.y; v.z = v.z * asr + bp.z; v.w = v.w * asr + bp.w;
         if (affine) { v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w; }
+        if constexpr (swiglu && lean && FULL) {
+            // SwiGLU on BOTH lanes of a gate / up pair (lanes L and L+8 of a 16-lane row).  The generic form below produces the four
+            // outputs of columns 4L..4L+3 on the gate lane and leaves the up lane idle through silu, split and statistics; here the
+            // pair swaps two values (one row_ror:8 each way) and each lane finishes two columns: gate lane 4L, 4L+1, up lane
+            // 4L+2, 4L+3.  Same values, same bytes, and the statistics associate exactly as in the generic loop
+            // ((x + y) + (z + w) per pair first, then the 8-lane tree), so they are bit-identical too.
+            const bool gl = (lane & 8) == 0;                                    // gate lane
+            const float sa = gl ? v.z : v.x, sb = gl ? v.w : v.y;              // what the partner needs
+            const float ra = dpp_f<0x128, 0xF>(sa), rb = dpp_f<0x128, 0xF>(sb);   // row_ror:8 = the partner's value
+            const float o0 = silu(gl ? v.x : ra) * (gl ? ra : v.z);
+            const float o1 = silu(gl ? v.y : rb) * (gl ? rb : v.w);
+            const int oc = ncol_base / 2 + 4 * ((lane & 15) & 7) + (gl ? 0 : 2);
+            if (have_stats) {
+                float s1 = o0 + o1, s2 = o0 * o0 + o1 * o1;
+                const float p1 = dpp_f<0x128, 0xF>(s1), p2 = dpp_f<0x128, 0xF>(s2);
+                s1 = gl ? s1 + p1 : p1 + s1;  s2 = gl ? s2 + p2 : p2 + s2;     // (x.. + y..) + (z.. + w..) on both lanes
+                s1 += dpp_f<0xB1, 0xF>(s1);  s2 += dpp_f<0xB1, 0xF>(s2);
+                s1 += dpp_f<0x4E, 0xF>(s1);  s2 += dpp_f<0x4E, 0xF>(s2);
+                s1 += dpp_f<0x141, 0xF>(s1); s2 += dpp_f<0x141, 0xF>(s2);
+                if ((lane & 15) == 0) part[lr + 4 * p] = make_float2(s1, s2);
+            }
+            const size_t row = (size_t)(m_first + p * 4);
+            if (have_c) *reinterpret_cast<float2*>(g.C + row * g.ldc + oc) = make_float2(o0, o1);
+            if (have_s) {
+                const float x0 = o0 * g.cs_scale, x1 = o1 * g.cs_scale;
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                f16x2 hi, lo;
+                hi[0] = (_Float16)x0; hi[1] = (_Float16)x1;
+                lo[0] = (_Float16)(x0 - (float)hi[0]); lo[1] = (_Float16)(x1 - (float)hi[1]);
+                unsigned char* q = g.Cs + row * g.ldcs * 4 + split_col_off(oc);
+                *reinterpret_cast<f16x2*>(q) = hi; *reinterpret_cast<f16x2*>(q + 64) = lo;
+            }
+            continue;
+        }
         if (ACT == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (ACT == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         else if (swiglu) {
