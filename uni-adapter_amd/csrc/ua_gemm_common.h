@@ -283,6 +283,11 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
     float4 vin[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) vin[p] = *reinterpret_cast<const float4*>(sp + p * 4 * EP_LD);
+    // Specialised loops: the 16 lanes of a row leave their (sum, sumsq) partials in the wave's staging area - free once the rows
+    // above are in registers; LDS operations of a wave execute in order - and one lane per row adds them after the loop in the
+    // association of the DPP tree of the generic loop (bit-identical statistics, ~1/4 of the instructions).  17 slots per row.
+    float2* const scr = reinterpret_cast<float2*>(const_cast<float*>(stage));
+    constexpr bool lds_stats = lean && FULL;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
         float4 v = vin[p];
@@ -302,15 +307,7 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
             const float o0 = silu(gl ? v.x : ra) * (gl ? ra : v.z);
             const float o1 = silu(gl ? v.y : rb) * (gl ? rb : v.w);
             const int oc = ncol_base / 2 + 4 * ((lane & 15) & 7) + (gl ? 0 : 2);
-            if (have_stats) {
-                float s1 = o0 + o1, s2 = o0 * o0 + o1 * o1;
-                const float p1 = dpp_f<0x128, 0xF>(s1), p2 = dpp_f<0x128, 0xF>(s2);
-                s1 = gl ? s1 + p1 : p1 + s1;  s2 = gl ? s2 + p2 : p2 + s2;     // (x.. + y..) + (z.. + w..) on both lanes
-                s1 += dpp_f<0xB1, 0xF>(s1);  s2 += dpp_f<0xB1, 0xF>(s2);
-                s1 += dpp_f<0x4E, 0xF>(s1);  s2 += dpp_f<0x4E, 0xF>(s2);
-                s1 += dpp_f<0x141, 0xF>(s1); s2 += dpp_f<0x141, 0xF>(s2);
-                if ((lane & 15) == 0) part[lr + 4 * p] = make_float2(s1, s2);
-            }
+            if (have_stats) scr[(lr + 4 * p) * 17 + (lane & 15)] = make_float2(o0 + o1, o0 * o0 + o1 * o1);
             const size_t row = (size_t)(m_first + p * 4);
             if (have_c) *reinterpret_cast<float2*>(g.C + row * g.ldc + oc) = make_float2(o0, o1);
             if (have_s) {
@@ -355,11 +352,14 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
             else if (!FULL) { if (nout0 >= n_out) t.x = 0.f; if (nout0 + 1 >= n_out) t.y = 0.f; if (nout0 + 2 >= n_out) t.z = 0.f; if (nout0 + 3 >= n_out) t.w = 0.f; }
             float s1 = (t.x + t.y) + (t.z + t.w);
             float s2 = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+            if constexpr (lds_stats) { scr[(lr + 4 * p) * 17 + (lane & 15)] = make_float2(s1, s2); }
+            else {
             s1 += dpp_f<0xB1, 0xF>(s1);  s2 += dpp_f<0xB1, 0xF>(s2);           // quad_perm [1,0,3,2]
             s1 += dpp_f<0x4E, 0xF>(s1);  s2 += dpp_f<0x4E, 0xF>(s2);           // quad_perm [2,3,0,1]
             s1 += dpp_f<0x141, 0xF>(s1); s2 += dpp_f<0x141, 0xF>(s2);          // row_half_mirror
             s1 += dpp_f<0x140, 0xF>(s1); s2 += dpp_f<0x140, 0xF>(s2);          // row_mirror
             if ((lane & 15) == 0) part[lr + 4 * p] = make_float2(s1, s2);
+            }
         }
         if (FULL && !swiglu) {
             if (have_c) *reinterpret_cast<float4*>(cp + p * cstep) = v;
@@ -381,6 +381,29 @@ __device__ __forceinline__ void epilogue_64x64_impl(const EpiArgs& g, const floa
         if ((lean ? (LEAN & 16) != 0 : true) && lane_ok) {
             if (pool32 && p >= 8) { pm2.x = fmaxf(pm2.x, v.x); pm2.y = fmaxf(pm2.y, v.y); pm2.z = fmaxf(pm2.z, v.z); pm2.w = fmaxf(pm2.w, v.w); }
             else { pm.x = fmaxf(pm.x, v.x); pm.y = fmaxf(pm.y, v.y); pm.z = fmaxf(pm.z, v.z); pm.w = fmaxf(pm.w, v.w); }
+        }
+    }
+    if constexpr (lds_stats) {
+        if (have_stats) {
+            // lane r adds the 16 partials of row r: xor-1 pairs, xor-2 pairs, the two quads of an 8-lane half (lane 7's order
+            // for the upper quad), the two halves - what lane 0 of the row holds after the generic loop's four DPP steps
+            const float2* rp = scr + lane * 17;
+            float2 l[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) l[j] = rp[j];
+            auto add = [](float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); };
+            float2 tot;
+            if constexpr (swiglu) {
+                float2 P[8];                                                    // the generic loop's per-lane values: gate + up lane
+#pragma unroll
+                for (int j = 0; j < 8; ++j) P[j] = add(l[j], l[j + 8]);
+                tot = add(add(add(P[0], P[1]), add(P[2], P[3])), add(add(P[7], P[6]), add(P[5], P[4])));
+            } else {
+                const float2 c0 = add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[7], l[6]), add(l[5], l[4])));
+                const float2 c15 = add(add(add(l[15], l[14]), add(l[13], l[12])), add(add(l[8], l[9]), add(l[10], l[11])));
+                tot = add(c0, c15);
+            }
+            part[lane] = tot;
         }
     }
     if (have_pool) {                                                 // max over this wave's 64 rows
