@@ -49,10 +49,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--chunk', type=int, default=124,
+    ap.add_argument('--chunk', type=int, default=31,
                     help='samples per rank per step = how many stream samples the encoder batches before the in-order replay consumes them '
-                         '(124 -> 248 clouds per forward; 31 was the default until the end of round 2: 474 vs 498 pc/s on one box, '
-                         'profiles/r02b_chunk_sweep.txt; 1 = the reference loader)')
+                         '(31 -> 62 clouds per forward: 256x256 GEMM tile counts land just under multiples of 256 CUs; larger chunks trade '
+                         'latency for launch tails: 62 -> +3 %, 124 -> +5 %, profiles/r02b_chunk_sweep.txt; 1 = the reference loader)')
     ap.add_argument('--depth', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-similarity', action='store_true')
