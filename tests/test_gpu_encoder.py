@@ -116,6 +116,43 @@ def test_folded_layernorms_track_the_layernorm_kernels_full_depth():
     assert d_f32_fold <= 3.0 * d_f32_k + 1e-5
 
 
+def test_folded_layernorm_falls_back_to_the_kernels_when_its_first_forward_check_fails(monkeypatch):
+    """The fold is checked on EVERY block of the first forward (max |x| against the fp16 range of the split residual stream,
+    mean^2/var of the rows whose one-pass statistics were written).  A failing check switches the encoder to the LayerNorm
+    kernels and re-runs the blocks: the output is then bit for bit the un-folded encoder's, first forward included."""
+    import warnings
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict, PointcloudEncoder
+    sd = O.make_uni3d_state_dict(5, trans_dim=256, embed_dim=128, enc_dim=512, depth=3)
+    pc = _clouds(3, 1024, 9).cuda()
+    ref = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=4, precision='split', fold_layernorm=False)
+    want = ref.encode_pc(pc)
+    ok = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=4, precision='split', fold_layernorm=True)
+    got_fold = ok.encode_pc(pc)
+    pe = ok.point_encoder
+    assert pe.fold_ln and pe._fold_checked and pe.fold_max_abs > 0.0 and pe.fold_max_abs < PointcloudEncoder.FOLD_MAX_ABS
+    assert (got_fold - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    m = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=4, precision='split', fold_layernorm=True)
+    m.point_encoder.FOLD_MAX_ABS = 0.5 * pe.fold_max_abs             # the same stream now 'overflows' the split copy
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        got = m.encode_pc(pc)
+    assert not m.point_encoder.fold_ln and any('switched off' in str(r.message) for r in rec)
+    assert torch.equal(got, want)
+    assert torch.equal(m.encode_pc(pc), want)                        # and stays on the kernels
+
+
+def test_split_schedule_ab_switch_disables_the_fold(monkeypatch):
+    """UA_SPLIT_SCHEDULE=8|2 (A/B main loops without the fold prologue) must not leave the folded GEMM calls in place."""
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    sd = O.make_uni3d_state_dict(5, trans_dim=128, embed_dim=64, enc_dim=512, depth=1)
+    monkeypatch.setenv('UA_SPLIT_SCHEDULE', '8')
+    m = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, precision='split')
+    assert not m.point_encoder.fold_ln
+    monkeypatch.delenv('UA_SPLIT_SCHEDULE')
+    m = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, precision='split')
+    assert m.point_encoder.fold_ln
+
+
 # ---------------------------------------------------------------- ULIP-2 PointBERT variant (section 8 A4b)
 def _golden(name):
     import os

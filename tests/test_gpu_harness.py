@@ -353,6 +353,70 @@ def test_owner_replay_mode_two_ranks_on_one_gpu(tmp_path):
     assert got['acc'] == ref_acc and torch.load(out + '.r1', weights_only=True)['acc'] == ref_acc
 
 
+def test_owner_mode_calibration_leaves_the_engine_untouched_and_rho_does_not_change_results():
+    """`TtaEngine.calibrate_replay_cost` (owner mode, W > 1) replays a few samples on the LIVE adaptation state and restores it:
+    every tensor and counter the stream carries must be bit-identical afterwards, and the stream must continue exactly as if
+    the calibration had never run.  The ratio it measures only moves the cut between rank 0's and the other ranks' encoder
+    blocks: features assembled from blocks cut with two different ratios (encoded as separate batches, as two ranks would)
+    give bit-identical final logits - the encoder is invariant to batch composition."""
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
+    from uni_adapter_amd.Uni_Adapter import TtaEngine, NOISE_STD
+    from uni_adapter_amd.stream import shard_counts
+    K, D, n, chunk = 10, 256, 12, 6
+    sd = synthetic.uni3d_state_dict(1, trans_dim=128, embed_dim=D, depth=1, device='cuda')
+    model = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, device='cuda')
+    text = synthetic.text_bank(K, D, 2)
+    xyz, rgb = synthetic.point_clouds(n, 1024, 3, device='cuda')
+    noise = torch.randn(n, 1024, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    tgt = torch.arange(n, device='cuda') % K
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+
+    def snapshot(e):
+        m, r = e.mode_dota_model, e.residuals
+        ts = dict(mu=m.mu, var=m.var, pi=m.pi, c=m.c, cc=m.class_counts, res=r.res, am=r.m, av=r.v, e=r.e, norm=r.norm,
+                  tickets=e.tickets, correct=e.correct)
+        if e.align_mfma:                  # text0 + res, kept current only by the matrix-core residual kernels
+            ts['t'] = r.t
+        return {k: v.clone() for k, v in ts.items()}, (int(e.i), int(m.t), int(r.step), int(e.count))
+
+    ref = TtaEngine(model, text, cfg, 2, res_learning=True, chunk=chunk)
+    eng = TtaEngine(model, text, cfg, 2, res_learning=True, chunk=chunk)
+    want = [ref.process_chunk(xyz[c:c + chunk], rgb[c:c + chunk], tgt[c:c + chunk], noise[c:c + chunk])[0] for c in range(0, n, chunk)]
+    got = [eng.process_chunk(xyz[:chunk], rgb[:chunk], tgt[:chunk], noise[:chunk])[0]]
+    before, counters = snapshot(eng)
+    eng.world, eng.replay_mode, eng.emulated = 2, 'owner', True          # act as rank 0 of a 2-rank owner-mode job for the calibration only
+    rho = eng.calibrate_replay_cost(xyz[:4], rgb[:4], noise[:4])
+    eng.world, eng.replay_mode = 1, 'owner'
+    assert 0.0 < rho <= 2.0 and rho == eng.replay_cost_ratio
+    after, counters2 = snapshot(eng)
+    assert counters == counters2
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    got.append(eng.process_chunk(xyz[chunk:], rgb[chunk:], tgt[chunk:], noise[chunk:])[0])
+    assert torch.equal(torch.cat(got), torch.cat(want))
+
+    outs = {}
+    for r_ in (0.0, 0.45):
+        e2 = TtaEngine(model, text, cfg, 2, res_learning=True, chunk=chunk)
+        fin = []
+        for c in range(0, n, chunk):
+            counts = shard_counts(chunk, 2, r_)
+            blocks, s0 = [], c
+            for cnt in counts:                                       # one encoder batch per (emulated) rank
+                if cnt:
+                    p_, c_, z_ = xyz[s0:s0 + cnt], rgb[s0:s0 + cnt], noise[s0:s0 + cnt]
+                    both = torch.stack([torch.cat((p_, c_), -1), torch.cat((p_ + NOISE_STD * z_, c_), -1)], 1)
+                    blocks.append(model.encode_pc(both.view(-1, 1024, 6)).view(cnt, 2, D))
+                s0 += cnt
+            feats = torch.cat(blocks, 0)
+            e2.encode_chunk = lambda *a, _f=feats: _f
+            fin.append(e2.process_chunk(xyz[c:c + chunk], rgb[c:c + chunk], tgt[c:c + chunk], noise[c:c + chunk])[0])
+        outs[r_] = torch.cat(fin)
+    assert shard_counts(chunk, 2, 0.0) != shard_counts(chunk, 2, 0.45)
+    assert torch.equal(outs[0.0], outs[0.45]) and torch.equal(outs[0.0], torch.cat(want))
+
+
 @pytest.mark.parametrize('family', ['ulip', 'openshape'])
 def test_harness_drives_the_other_encoder_families(family):
     """test_zeroshot_3d_core with a ULIP-2 / OpenShape model: TtaEngine only needs `encode_pc(B,N,6)`."""

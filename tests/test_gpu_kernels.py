@@ -1357,3 +1357,23 @@ def test_gemm_split_every_tile_is_written_once_under_the_blocked_tile_walk(ua, N
         ua.call('ua_gemm_split', As.data_ptr(), K, 1.0, Ws.data_ptr(), K, 256.0, ua.ptr(Cd), N, M, N, K, C.byref(e), ua.stream_ptr())
         ref = (A.double() @ W.double().T).float()
         assert (Cd - ref).abs().max().item() < 1e-4, (M, N)
+
+
+@pytest.mark.parametrize('n', [200, 448, 1160])
+def test_spd_inverse_multi_tile_against_fp64(ua, n):
+    """The blocked SPD inverse with its Newton-Schulz refinement at sizes where `ua_gemm` runs several 128 x 128 tiles per row
+    panel (the cluster cache reaches K * shot_capacity prototypes).  The refinement product goes to a third buffer: written in
+    place, a finished tile overwrote columns that sibling tiles of its row panel were still reading as the A operand, and the
+    raced entries kept the previous iterate's accuracy.  Run twice: the result must also be reproducible bit for bit."""
+    from uni_adapter_amd.dota import SpdInverse
+    g = torch.Generator().manual_seed(n)
+    Q = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = (Q @ Q.T / n + 0.5 * torch.eye(n, dtype=torch.float64))                  # SPD, condition number of a few tens
+    inv = SpdInverse(torch.device('cuda'))
+    Ad = dev(A.float())
+    X1 = inv(Ad).clone(); X2 = inv(Ad).clone()
+    assert torch.equal(X1, X2)
+    ref = torch.linalg.inv(A)
+    err = (X1.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    resid = (X1.cpu().double() @ A - torch.eye(n, dtype=torch.float64)).abs().max().item()
+    assert err < 2e-5 and resid < 2e-4, (err, resid)

@@ -26,6 +26,8 @@ from .dota_mixture import DOTA_mix
 from .stream import (REPLAY_COST_RATIO, agree_on_ratio, broadcast_from_owner, gather_deltas, gather_feature_blocks, gather_features, shard_block,
                      shard_counts, shard_indices)
 
+logger = logging.getLogger(__name__)
+
 LOGIT_SCALE = 100.0          # Uni_Adapter.py:57
 NOISE_STD = 0.05             # Uni_Adapter.py:420
 RES_STEPS = 10               # Uni_Adapter.py:467
@@ -153,6 +155,7 @@ class TtaEngine:
             # (rank, world): act as one rank of a W-rank job without a process group - the caller moves the
             # buffers between engines itself (lock-step tests of the 'delta' mode, tools/emulate_scaling.py)
             self.rank, self.world = int(emulated_rank[0]), int(emulated_rank[1])
+        self.emulated = emulated_rank is not None
         # where the sequential cache replay runs when W > 1 (stream.py): 'owner' = rank 0 only, with a
         # smaller encoder share for rank 0; 'replicated' = every rank replays everything
         self.replay_mode = replay_mode or os.environ.get('UA_REPLAY_MODE', 'owner')
@@ -184,7 +187,7 @@ class TtaEngine:
         K, D, M, dev = self.K, self.D, self.M, self.dev
         e = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)
         self.fh, self.fa = e(1, D), e(1, D)
-        self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)
+        self.z, self.prob, self.ent, self.dz = e(1, K), e(1, K), e(1), e(1, K)      # (dz: unused in 'class' mode - scores live in the exchange buffer)
         # UA_ALIGN_PATH=mfma runs the residual loop on the matrix cores (csrc/ua_align_mfma.hip) when the shape is inside its
         # envelope.  Opt-in: at K = 40 the two GEMMs are 0.05 GFLOP - the step is bound by kernel floors and per-CU L2
         # bandwidth, not arithmetic, and the VALU kernels (work spread over 160-400 workgroups) are faster
@@ -264,8 +267,13 @@ class TtaEngine:
             r1.record(); torch.cuda.synchronize()
             rep_ms = r0.elapsed_time(r1) / reps / n
             self.load_state_dict(saved)
+            self.tickets.zero_()                       # (every ua_align_step leaves its hand-off counters at zero; stated, not assumed)
+            self.last_loss = None
         # (the replay measured alone; beside rank 0's own encoder share it runs ~15 % slower - tools/emulate_scaling.py)
-        self.replay_cost_ratio = agree_on_ratio(1.15 * rep_ms, enc_ms, self.world, self.group, self.dev)
+        self.replay_cost_ratio = agree_on_ratio(1.15 * rep_ms, enc_ms, 1 if self.emulated else self.world, self.group, self.dev)
+        if self.rank == 0:
+            logger.info('owner-mode replay / encoder cost ratio rho = %.4f (replay %.3f ms, encoder %.3f ms per sample)',
+                        self.replay_cost_ratio, rep_ms, enc_ms)
         return self.replay_cost_ratio
 
     # -- encoder part: this rank's share of the chunk -------------------------------------
@@ -441,12 +449,15 @@ class TtaEngine:
     #    then the fusion of the chunk from the W gathered buffers (two halves so that W ranks can be driven in lock-step from
     #    one process).  Exact because, with residual learning off, nothing the fusion produces feeds back into the state: fit
     #    takes the zero-shot prob_map (Uni_Adapter.py:417,430) and mean(c) is only read by the fusion weight (:491). ---------
-    def _class_bufs(self, n):
-        if getattr(self, '_cls_n', 0) < n:
-            self._cls_n = n
+    def _class_bufs(self, n, fresh=False):
+        """Per-chunk buffers of the class-sharded replay, allocated on the stream that runs the replay (the caching allocator
+        hands a block back only in that stream's order): the exchange buffer is read by the collective while the next chunk's
+        pack kernels may already be enqueued, so no buffer is shared between chunks.  `fresh` starts a chunk; the fusion half
+        of the same chunk picks the clip-logit buffer up again."""
+        if fresh or getattr(self, 'zbuf', None) is None or self.zbuf.shape[0] != n:
             self.zbuf = torch.empty(n, self.K, device=self.dev)
             self.xbuf = torch.zeros(n, self.class_per + 2, device=self.dev)
-        return self.zbuf[:n], self.xbuf[:n]
+        return self.zbuf, self.xbuf
 
     def class_local_chunk(self, feats):
         """feats (n,2,D).  Per sample: clip logits over all K (every rank), predict + fit + fit on classes [k0,k1) of the
@@ -455,7 +466,7 @@ class TtaEngine:
         n = feats.shape[0]
         k0, kl = self.class_k0, self.class_k1 - self.class_k0
         mdl, st = self.mode_dota_model, lib.stream_ptr()
-        zbuf, xbuf = self._class_bufs(n)
+        zbuf, xbuf = self._class_bufs(n, fresh=True)
         feats = feats.contiguous()
         row = 4 * k0 * M
         for j in range(n):

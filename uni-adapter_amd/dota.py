@@ -39,7 +39,7 @@ class DOTA(torch.nn.Module):
         self.Lambda = (torch.eye(D, dtype=torch.float64, device=dev) / float(cfg['sigma'])).half().contiguous()
         self._A = torch.empty(D, D, device=dev); self._inv = torch.empty(D, D, device=dev)
         self._W = torch.empty(D, K, dtype=torch.float16, device=dev)
-        self._U = torch.empty(D, D, device=dev); self._X2 = torch.empty(D, D, device=dev)
+        self._U = torch.empty(D, D, device=dev); self._X2 = torch.empty(D, D, device=dev); self._Xn = torch.empty(D, D, device=dev)
         self.refine_steps = 3
         self._neg = torch.full((D,), -1.0, device=dev)
         self.update_prior = prior_pre_steps is not None                                             # :32-39
@@ -72,12 +72,16 @@ class DOTA(torch.nn.Module):
         # The explicit block inverse in fp32 is ~cond(A) less accurate than an LU solve (measured on the g10 stream:
         # max error 11 vs 0.02 at |Lambda| = 6.8e3).  Newton-Schulz steps X <- 2X - X A X (two more GEMMs each, on the
         # symmetrised iterate) square the error down to the fp32 floor (0.4 after two steps, 0.1 after three).
-        X, U, X2 = self._inv, self._U, self._X2
+        # The product is written to a third buffer (ping-pong): ua_gemm runs one tile per workgroup, so with C aliasing
+        # the A operand a finished tile would overwrite columns its row panel's other tiles are still reading.
+        X, Xn, U, X2 = self._inv, self._Xn, self._U, self._X2
         for _ in range(self.refine_steps):
             X.copy_(0.5 * (X + X.t()))
             torch.mul(X, 2.0, out=X2)
             self._gemm(X, self._A, U, D, D, D)                               # U = X @ A^T = X A
-            self._gemm(X, U, X, D, D, D, neg=True, residual=X2)              # X = 2X - X @ U^T = 2X - X A X
+            self._gemm(X, U, Xn, D, D, D, neg=True, residual=X2)             # Xn = 2X - X @ U^T = 2X - X A X
+            X, Xn = Xn, X
+        self._inv, self._Xn = X, Xn
         lib.call('ua_to_half', lib.ptr(self._inv), self.Lambda.data_ptr(), self._inv.numel(), lib.stream_ptr())
 
     def _gemm(self, A, W, C, M, N, K, neg=False, residual=None):
@@ -156,10 +160,11 @@ class SpdInverse:
         Ap[:n, :n] = A
         X = torch.empty(N, N, device=self.dev)
         self._invert(Ap, X)
-        U, X2 = torch.empty(N, N, device=self.dev), torch.empty(N, N, device=self.dev)
+        U, X2, Xn = (torch.empty(N, N, device=self.dev) for _ in range(3))
         for _ in range(self.refine_steps):
             X.copy_(0.5 * (X + X.t()))
             torch.mul(X, 2.0, out=X2)
             self._gemm(X, Ap, U, N, N, N)
-            self._gemm(X, U, X, N, N, N, neg=True, residual=X2)
+            self._gemm(X, U, Xn, N, N, N, neg=True, residual=X2)              # never in place: see DOTA.update
+            X, Xn = Xn, X
         return X[:n, :n]

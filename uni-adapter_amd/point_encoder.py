@@ -172,6 +172,8 @@ class PointcloudEncoder(nn.Module):
         # UA_FOLD_LN=0 / fold_layernorm=False keeps the LN kernels (A/B aid)
         if fold_layernorm is None:
             fold_layernorm = os.environ.get('UA_FOLD_LN', '1') != '0'
+        if os.environ.get('UA_SPLIT_SCHEDULE', '16') != '16':
+            fold_layernorm = False      # the A/B main loops (schedules 8 and 2) have no fold prologue: ua_gemm_split returns UA_EUNSUPPORTED
         self.fold_ln = bool(fold_layernorm) and sp
         self._fold_checked = False
         if self.group_size not in (32, 64):
@@ -377,26 +379,40 @@ class PointcloudEncoder(nn.Module):
         ws.update(xs=e(rows, Cd), st_x=e((Cd + 255) // 256, rows, 2), st_h=e((2 * Hp + 255) // 256, rows, 2),
                   mr_x=e(rows, 2), mr_h=e(rows, 2))
 
+    FOLD_MAX_ABS = 3.0e4          # fp16 'hi' of the residual stream's split copy overflows at 65504; keep a factor 2 of headroom
+    FOLD_MAX_MEAN2_OVER_VAR = 1.0e4   # one-pass (sum, sumsq) statistics in fp32 lose log10(1 + mean^2/var) of their 7.2 digits
+
     @torch.no_grad()
-    def _fold_check(self, w, rows, Cd):
-        """Once per encoder: the one-pass row statistics of the folded LayerNorms (sum, sum of squares in fp32 partials) lose
-        log10(1 + mean^2/var) digits.  Look at the last block's statistics of the first forward and say so if any token row has
-        |mean| > 10 sigma (measured there: 7x the LayerNorm kernel's error, still 5e-6 relative)."""
-        self._fold_checked = True
+    def _fold_probe(self, w, rows, Cd, b, x, have_x, have_h):
+        """First forward only: magnitude of the residual stream after block `b` and mean^2/var of the token rows whose one-pass
+        statistics this block wrote (x after proj / fc2, the hidden activation after fc1).  Returns (amax |x| * scale, worst ratio)."""
         worst = 0.0
-        for key, n in (('st_x', Cd), ('st_h', self.blocks[-1].H)):
+        for key, n, have in (('st_x', Cd, have_x), ('st_h', b.H, have_h)):
             st = w.get(key)
-            if st is None or (key == 'st_h' and self.blocks[-1].f_w2 is None):    # (no sub-LN: no hidden statistics were written)
+            if st is None or not have:
                 continue
-            parts = (Cd + 255) // 256 if key == 'st_x' else ((2 if self.blocks[-1].act == ACT_SWIGLU else 1) * self.blocks[-1].Hp + 255) // 256
+            parts = (Cd + 255) // 256 if key == 'st_x' else ((2 if b.act == ACT_SWIGLU else 1) * b.Hp + 255) // 256
             tot = st[:parts, :rows].double().sum(0)
             mean = tot[:, 0] / n
             var = (tot[:, 1] / n - mean * mean).clamp_min(1e-30)
             worst = max(worst, float((mean * mean / var).max()))
-        self.fold_mean2_over_var = worst
+        return float(x[:rows].abs().max()) * X_SPLIT_SCALE, worst
+
+    def _fold_verdict(self, amax, worst):
+        """Once per encoder, from the statistics of EVERY block of the first forward: keep the folded LayerNorms only if the split
+        copy of the residual stream cannot overflow fp16 and no token row is so far from zero mean that its one-pass variance is
+        noise; otherwise fall back to the LayerNorm kernels.  Returns True if the fold stays on."""
+        self._fold_checked = True
+        self.fold_mean2_over_var, self.fold_max_abs = worst, amax
         if worst > 100.0:
             warnings.warn(f'folded LayerNorm: a token row has mean^2/var = {worst:.3g} (> 100); its one-pass statistics keep '
-                          f'{7.2 - math.log10(1 + worst):.1f} of 7.2 digits - consider fold_layernorm=False / UA_FOLD_LN=0')
+                          f'{7.2 - math.log10(1 + worst):.1f} of 7.2 digits')
+        ok = amax < self.FOLD_MAX_ABS and worst <= self.FOLD_MAX_MEAN2_OVER_VAR and math.isfinite(amax) and math.isfinite(worst)
+        if not ok:
+            warnings.warn(f'folded LayerNorm switched off for this encoder: max |x| * scale = {amax:.3g} (limit {self.FOLD_MAX_ABS:.0e}), '
+                          f'mean^2/var = {worst:.3g} (limit {self.FOLD_MAX_MEAN2_OVER_VAR:.0e}); running the LayerNorm kernels instead')
+            self.fold_ln = False
+        return ok
 
     def _run_blocks(self, w, Bc):
         """The transformer blocks on the token rows of w['x'] (in place); returns w['x']."""
@@ -409,6 +425,9 @@ class PointcloudEncoder(nn.Module):
         x = w['x']
         first = True
         nb = len(self.blocks)
+        probing = self.fold_ln and not self._fold_checked and nb > 0
+        if probing:                                   # first forward of a folded encoder: keep the input for a possible re-run
+            x_in, amax, worst = x[:rows].clone(), 0.0, 0.0
         for bi, b in enumerate(self.blocks):
             if self.variant == 'ulip' and not first:      # x = block(x + pos) in every block (pointbert/point_encoder.py:95-98)
                 lib.call('ua_add_pos', x.data_ptr(), w['pos'].data_ptr(), self.cls_pos.data_ptr(), Bc, G, Cd, st)
@@ -479,6 +498,9 @@ class PointcloudEncoder(nn.Module):
                       alg_flops=2.0 * rows * Cd * b.H, a_scale=b.hraw_scale, **kw)
                 if not last and x_parts > 4:
                     _row_stats(w['st_x'], x_parts, rows, Cd, self.ln_eps, w['mr_x'])
+                if probing:
+                    a, r = self._fold_probe(w, rows, Cd, b, x, not last, f2 is not None)
+                    amax, worst = max(amax, a), max(worst, r)
                 continue
             _gemm(att, Cd, b.wproj, x, Cd, rows, Cd, Cd, bias=b.bproj, scale=b.gamma1, residual=x, ldr=Cd, a_scale=s_att)
             s2 = b.ln2_scale if sp else None
@@ -496,8 +518,9 @@ class PointcloudEncoder(nn.Module):
                 lib.call('ua_split_f16', hid.data_ptr(), ld_h, w['hidn'].data_ptr(), ld_h, rows, b.H, Hp, 1.0, st)
                 hid, s_h = w['hidn'], 1.0
             _gemm(hid, ld_h, b.w2, x, Cd, rows, Cd, Hp, bias=b.b2, scale=b.gamma2, residual=x, ldr=Cd, alg_flops=2.0 * rows * Cd * b.H, a_scale=s_h)
-        if self.fold_ln and not self._fold_checked and self.blocks:
-            self._fold_check(w, rows, Cd)
+        if probing and not self._fold_verdict(amax, worst):
+            x[:rows].copy_(x_in)                        # the fold is off now: run the blocks again on the LayerNorm kernels
+            return self._run_blocks(w, Bc)
         return x
 
     @torch.no_grad()
