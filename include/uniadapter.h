@@ -35,7 +35,7 @@ extern "C" {
 #define UA_EWORKSPACE    -4   /* workspace too small                                          */
 #define UA_ELAUNCH       -5   /* hipGetLastError() != hipSuccess after the launch             */
 
-#define UA_VERSION 102        /* 0.1.1: round 2 (ua_fuse_logits_sharded per chunk, ua_tta_state extended, MFMA similarity / alignment entry points) */
+#define UA_VERSION 103        /* 0.1.2: round 3 (ua_tta_state.replay_lean, ua_gemm_split_set_persistent) */
 
 int         ua_version(void);
 const char* ua_strerror(int code);
@@ -247,6 +247,13 @@ int ua_gemm_split(const void* A, int64_t lda, float a_scale, const void* W, int6
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                   const ua_gemm_epilogue* ep, void* stream);
 
+/* Tuning knob of ua_gemm_split (process-wide, not a data-path entry): mode 1 = launches of more than one round of tiles run as
+ * <= one resident workgroup per CU walking the tile list (no workgroup dispatch between a CU's tiles), 2 = only launches of
+ * >= 8 rounds, 0 = one workgroup per tile always (the default: measured 0..+4 % slower to 3 % faster by shape, nothing on
+ * the whole encoder - DESIGN.md section 7), -1 = take the default from the environment (UA_SPLIT_PERSIST) at the next
+ * call.  Results are bit-identical in every mode.                                                                      */
+int ua_gemm_split_set_persistent(int32_t mode);
+
 /* Row statistics for the folded LayerNorm: partials (parts, ld_stats) float2 as written through
  * ua_gemm_epilogue.row_stats_out -> mean_rstd[m] = (mean, 1/sqrt(var + eps)) over n values per row (biased variance,
  * F.layer_norm); the tiles are summed in index order in fp64, so the result does not depend on scheduling.          */
@@ -350,6 +357,11 @@ typedef struct {
     int32_t align_mfma;                                              /* 0: VALU kernels, 1: MFMA kernels  */
     float  *t, *U;                                                   /* text0 + res (K,D); scratch (K,K,M) */
     void   *align_ws; size_t align_ws_bytes;                         /* ua_align_mfma_workspace_bytes      */
+    /* VALU residual step as ua_align_loss + ua_align_backward + ua_residual_adam (bit-identical to ua_align_step) instead of the
+     * one-launch ua_align_step: two launches more per Adam step, but ~45 % of the CU-time (the loss statistics are computed once,
+     * not by each of the 4 K workgroups) - for a replay that shares the GPU with the encoder (throughput), not for a replay
+     * rank that other GPUs wait on (latency). */
+    int32_t replay_lean;
 } ua_tta_state;
 
 /* feats (n,2,D): [:,0] encoder output of the sample, [:,1] of its augmented copy.

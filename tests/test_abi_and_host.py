@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(so, n), f'{n} declared in include/uniadapter.h but not exported'
     assert set(lib.SIGNATURES) | {'ua_version', 'ua_strerror', 'ua_gmm_loglik_mfma_workspace_bytes', 'ua_align_mfma_workspace_bytes', 'ua_align_mfma_supported'} == set(names)
-    assert lib.version() == 102
+    assert lib.version() == 103
     assert 'envelope' in lib.strerror(-3) and lib.strerror(0) == 'ok'
 
 

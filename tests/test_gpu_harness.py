@@ -353,6 +353,33 @@ def test_owner_replay_mode_two_ranks_on_one_gpu(tmp_path):
     assert got['acc'] == ref_acc and torch.load(out + '.r1', weights_only=True)['acc'] == ref_acc
 
 
+def test_lean_replay_is_bit_identical_to_the_one_launch_residual_step():
+    """ua_tta_state.replay_lean: the residual step as ua_align_loss + ua_align_backward + ua_residual_adam (less CU-time, for a
+    replay that shares the GPU with the encoder) against the one-launch ua_align_step (less latency): same final logits,
+    predictions, GMM state, residuals and Adam moments, bit for bit, over a stream with residual learning."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = torch.Generator().manual_seed(21)
+    K, D, M, n = 40, 1024, 8, 12
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    lab = torch.randint(0, K, (n,), generator=g)
+    f0 = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(n, D, generator=g), dim=1)
+    f1 = torch.nn.functional.normalize(f0 + 0.02 * torch.randn(n, D, generator=g), dim=1)
+    feats = torch.stack([f0, f1], 1).cuda().contiguous()
+    cfg = {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}
+    outs = []
+    for lean in (False, True):
+        e = TtaEngine(None, text, cfg, M, res_learning=True, chunk=n, replay_lean=lean)
+        assert e.replay_lean == lean and e._state.replay_lean == int(lean)
+        e.encode_chunk = lambda *a, _f=feats: _f
+        dummy = torch.zeros(n, 8, 3)
+        fin, _, pred = e.process_chunk(dummy, dummy, lab.cuda().int(), dummy)
+        e.synchronize()
+        m, r = e.mode_dota_model, e.residuals
+        outs.append([t.clone() for t in (fin, pred, m.mu, m.var, m.pi, m.c, r.res, r.m, r.v, r.e, r.norm)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_owner_mode_calibration_leaves_the_engine_untouched_and_rho_does_not_change_results():
     """`TtaEngine.calibrate_replay_cost` (owner mode, W > 1) replays a few samples on the LIVE adaptation state and restores it:
     every tensor and counter the stream carries must be bit-identical afterwards, and the stream must continue exactly as if

@@ -121,7 +121,7 @@ class TtaEngine:
 
     def __init__(self, model, text_features, dota_cfg, num_modes, res_learning=True, chunk=16, device=None,
                  log_alignment_every=0, dist_group=None, composite=True, overlap=False, replay_mode=None,
-                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False, emulated_rank=None, align_path=None):
+                 replay_cost_ratio=REPLAY_COST_RATIO, two_stream_encode=False, emulated_rank=None, align_path=None, replay_lean=None):
         self.model = model
         self.composite = bool(composite) and not log_alignment_every
         # overlap=True: the in-order cache replay of chunk c runs on a second HIP stream while the
@@ -202,6 +202,15 @@ class TtaEngine:
         else:
             self.L = self.joint = self.gll = self.ge = self.inv_var = self.row_const = None
             self.loss = e(1)
+        # Residual step in three launches (loss | backward | Adam) instead of the one-launch ua_align_step - bit-identical, ~45 % of
+        # the CU-time, two more launches per Adam step: right where the replay shares the GPU with this rank's own encoder work
+        # (its CU-time comes out of the encoder's), wrong for a dedicated replay rank that the encoder ranks wait on.
+        env_lean = os.environ.get('UA_REPLAY_LEAN')
+        if replay_lean is None and env_lean is not None:
+            replay_lean = env_lean != '0'
+        if replay_lean is None:
+            replay_lean = self.overlap and (self.world == 1 or self.replay_mode in ('replicated', 'streams'))
+        self.replay_lean = bool(replay_lean)
         self.tickets = torch.zeros(K, dtype=torch.int32, device=self.dev)      # hand-off counters of ua_align_step
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits
         self.count = 0
@@ -225,6 +234,7 @@ class TtaEngine:
             s.L, s.joint, s.grad_ll, s.grad_e = (t.data_ptr() for t in (self.L, self.joint, self.gll, self.ge))
             s.inv_var, s.row_const = self.inv_var.data_ptr(), self.row_const.data_ptr()
         s.tickets = self.tickets.data_ptr()
+        s.replay_lean = int(self.replay_lean)
         if self.res_learning and self.align_mfma:
             s.align_mfma = 1
             s.t, s.U = r.t.data_ptr(), self.U.data_ptr()

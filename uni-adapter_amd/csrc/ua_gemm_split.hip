@@ -354,14 +354,13 @@ __device__ __forceinline__ void split_mainloop8(const SplitArgs& g, int m0, int 
 #undef UA_MFMA16
 }
 
-template <int SCHED, int TERMS = 3>
-__global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
+template <int SCHED, int TERMS>
+__device__ __forceinline__ void split_tile(const SplitArgs& g, const int bid, const int zero) {
     // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by blockIdx.  The tiles of a
     // partial last row panel (here the 32 CLS rows: almost no MFMA work but a full K walk) take the
     // FIRST blockIdx values, so they overlap with the first round instead of forming a tail; the
     // full tiles follow, chunked so that every XCD (blockIdx % 8) owns a contiguous band of row
     // panels (A-panel reuse in its L2) and all XCDs get the same number of full tiles (+-1).
-    const int bid = blockIdx.x;
 #ifdef UA_SPLIT_TRACE
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long ct0 = __builtin_amdgcn_s_memtime();
@@ -396,7 +395,9 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
         tn = cb * BC + o2 % bc;
     }
     const int m0 = tm * SBM, n0 = tn * SBN;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // (`zero` is 0: the literal in the one-tile kernel; in the persistent kernel an opaque per-iteration SGPR, so that nothing derived
+    //  from the lane id is hoisted out of the tile loop and kept in registers across the whole body)
+    const int tid = threadIdx.x + zero, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -545,6 +546,25 @@ __global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
 #endif
 }
 
+template <int SCHED, int TERMS = 3>
+__global__ void __launch_bounds__(512, 2) gemm_split_kernel(SplitArgs g) {
+    split_tile<SCHED, TERMS>(g, blockIdx.x, 0);
+}
+
+// Persistent form: gridDim.x (a multiple of 8, at most one workgroup per CU) resident workgroups walk the tile list in the order
+// the hardware dispatcher would have dealt it (virtual block id = blockIdx + i * gridDim keeps blockIdx % 8, i.e. the XCD band of
+// split_tile's tile order), so a CU goes from one tile's last store to the next tile's first DMA without waiting for a new
+// workgroup to be dispatched.
+template <int SCHED, int TERMS = 3>
+__global__ void __launch_bounds__(512, 2) gemm_split_persistent_kernel(SplitArgs g) {
+    for (int vb = blockIdx.x; vb < g.n_tiles; vb += gridDim.x) {
+        int zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        split_tile<SCHED, TERMS>(g, vb, zero);
+        __syncthreads();                       // every wave is done with the staging area before the next tile's DMA overwrites it
+    }
+}
+
 // fp32 -> H32L32, one thread per 4 columns
 __global__ void __launch_bounds__(256)
 split_f16_kernel(const float* __restrict__ x, long long ldx, unsigned char* __restrict__ y, long long ldy,
@@ -581,6 +601,8 @@ extern "C" int ua_split_f16(const float* x, int64_t ldx, void* y, int64_t ldy, i
 
 static int g_sched = -1;
 static int g_block_order = -1;
+static int g_persist = -1;
+extern "C" int ua_gemm_split_set_persistent(int32_t mode) { g_persist = mode; return UA_OK; }
 #ifdef UA_SPLIT_TRACE
 extern "C" void ua_gemm_split_set_schedule(int v) { g_sched = v; }
 extern "C" void ua_gemm_split_set_tile_order(int v) { g_block_order = v; }
@@ -627,7 +649,20 @@ extern "C" int ua_gemm_split(const void* A, int64_t lda, float a_scale, const vo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_persistent_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return UA_ELAUNCH;
         attr_set = true;
+    }
+    // UA_SPLIT_PERSIST=1 / ua_gemm_split_set_persistent(1): resident workgroups walk the tile list (launches of more than one round only)
+    if (g_persist < 0) { const char* e = getenv("UA_SPLIT_PERSIST"); g_persist = e ? atoi(e) : 0; }
+    const int persist = g_persist;
+    static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                                 return n >= 8 ? n / 8 * 8 : 8; }();
+    // mode 2 (default): only where it measured faster - launches of >= 8 rounds of tiles (fc1 of a >= 62-cloud forward -3 %; 1-6 rounds 0..+3 %)
+    if (sched == 16 && persist && g.n_tiles > n_cu && (persist == 1 || g.n_tiles >= 8 * n_cu)) {
+        hipLaunchKernelGGL(gemm_split_persistent_kernel<16>, dim3(n_cu), dim3(512), lds, ua::as_stream(stream), g);
+        UA_LAUNCH_CHECK();
+        return UA_OK;
     }
     if (sched == 16) hipLaunchKernelGGL(gemm_split_kernel<16>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);
     else if (sched == 8) hipLaunchKernelGGL(gemm_split_kernel<8>, dim3(g.n_tiles), dim3(512), lds, ua::as_stream(stream), g);

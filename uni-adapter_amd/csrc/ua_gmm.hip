@@ -74,16 +74,26 @@ __device__ __forceinline__ float log_normal(float x) {
 }
 
 // sum_d ln(max(var+eps,1e-8)) over the wave's row (all lanes get the total)
+// UA_GMM_SUM4: the four terms of a float4 are added in fp32, (x + z) + (y + w), before they join the fp64 sum: 2 instead of 8
+// instructions per float4 and accumulator.  The partial sums are ~40 in magnitude (error <= 4e-6 each, unbiased), 256 of them per
+// row: ~5e-5 on sums that are rounded to fp32 at an ulp of 2.4e-4 .. 1e-3 afterwards.  All helpers use the same association, so the
+// kernels stay bit-identical to one another.
+#ifndef UA_GMM_SUM4
+#define UA_GMM_SUM4 1          // -DUA_GMM_SUM4=0: every term joins the fp64 sum on its own (the round-1/2 arithmetic; A/B aid)
+#endif
+#if UA_GMM_SUM4
+#define UA_ACC4(acc, a, b, c, d) acc += (double)(((a) + (c)) + ((b) + (d)))
+#else
+#define UA_ACC4(acc, a, b, c, d) do { acc += (double)(a); acc += (double)(b); acc += (double)(c); acc += (double)(d); } while (0)
+#endif
+
 template <int VEC>
 __device__ __forceinline__ double row_logdet(const Row<VEC>& r, float eps) {
     double acc = 0.0;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        acc += (double)log_normal(reg_var(r.var[v].x, eps));
-        acc += (double)log_normal(reg_var(r.var[v].y, eps));
-        acc += (double)log_normal(reg_var(r.var[v].z, eps));
-        acc += (double)log_normal(reg_var(r.var[v].w, eps));
-    }
+    for (int v = 0; v < VEC; ++v)
+        UA_ACC4(acc, log_normal(reg_var(r.var[v].x, eps)), log_normal(reg_var(r.var[v].y, eps)),
+                log_normal(reg_var(r.var[v].z, eps)), log_normal(reg_var(r.var[v].w, eps)));
     return wave_sum(acc);
 }
 
@@ -98,11 +108,9 @@ __device__ __forceinline__ double row_maha(const Row<VEC>& r, const float* x, fl
     for (int v = 0; v < VEC; ++v) {
         float4 xv = px[v * 64 + lane];
         if (ROUND16) { xv.x = round_fp16(xv.x); xv.y = round_fp16(xv.y); xv.z = round_fp16(xv.z); xv.w = round_fp16(xv.w); }
-        float d;
-        d = xv.x - r.mu[v].x; acc += (double)div_nr(d * d, reg_var(r.var[v].x, eps));
-        d = xv.y - r.mu[v].y; acc += (double)div_nr(d * d, reg_var(r.var[v].y, eps));
-        d = xv.z - r.mu[v].z; acc += (double)div_nr(d * d, reg_var(r.var[v].z, eps));
-        d = xv.w - r.mu[v].w; acc += (double)div_nr(d * d, reg_var(r.var[v].w, eps));
+        const float dx = xv.x - r.mu[v].x, dy = xv.y - r.mu[v].y, dz = xv.z - r.mu[v].z, dw = xv.w - r.mu[v].w;
+        UA_ACC4(acc, div_nr(dx * dx, reg_var(r.var[v].x, eps)), div_nr(dy * dy, reg_var(r.var[v].y, eps)),
+                div_nr(dz * dz, reg_var(r.var[v].z, eps)), div_nr(dw * dw, reg_var(r.var[v].w, eps)));
     }
     return wave_sum(acc);
 }
@@ -125,19 +133,20 @@ __device__ __forceinline__ void row_logdet_maha(const Row<VEC>& r, const float* 
     const float4* pb = reinterpret_cast<const float4*>(xb);
     double al = 0.0, aa = 0.0, ab = 0.0;
 #define UA_LM(F)                                                                        \
-    {                                                                                   \
-        const float rv = reg_var(r.var[v].F, eps);                                      \
-        const float rc = __builtin_amdgcn_rcpf(rv);                                     \
-        al += (double)log_normal(rv);                                                   \
-        float d = xav.F - r.mu[v].F; aa += (double)div_r(d * d, rv, rc);                \
-        if (TWO) { d = xbv.F - r.mu[v].F; ab += (double)div_r(d * d, rv, rc); }         \
-    }
+        const float rv_##F = reg_var(r.var[v].F, eps);                                  \
+        const float rc_##F = __builtin_amdgcn_rcpf(rv_##F);                             \
+        const float ln_##F = log_normal(rv_##F);                                        \
+        const float da_##F = xav.F - r.mu[v].F, qa_##F = div_r(da_##F * da_##F, rv_##F, rc_##F);   \
+        const float db_##F = xbv.F - r.mu[v].F, qb_##F = TWO ? div_r(db_##F * db_##F, rv_##F, rc_##F) : 0.f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const float4 xav = pa[v * 64 + lane];
         float4 xbv = xav;
         if (TWO) xbv = pb[v * 64 + lane];
         UA_LM(x) UA_LM(y) UA_LM(z) UA_LM(w)
+        UA_ACC4(al, ln_x, ln_y, ln_z, ln_w);
+        UA_ACC4(aa, qa_x, qa_y, qa_z, qa_w);
+        if (TWO) UA_ACC4(ab, qb_x, qb_y, qb_z, qb_w);
     }
 #undef UA_LM
     ld = wave_sum(al); ma = wave_sum(aa);
@@ -155,6 +164,61 @@ __device__ __forceinline__ float lse_modes_wave(const float* j, int M, int lane)
     float s = 0.f;
     for (int i = 0; i < M; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), i));
     return mx + logf(s);
+}
+
+// ---- two columns per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) for the stream kernel --------------------
+// gmm_step1_kernel saturates the VALU issue port (profiles/r03_gmm_step_phase_trace.txt: the youngest wave of every SIMD is never
+// parked); on gfx950 a packed fp32 FMA costs 3.5 cycles per SIMD for two columns against 3.2 for one (tools/_probe/valu_rate.hip).
+// Every operation below is the same IEEE operation on the same operands as in the scalar helpers above - only two at a time -
+// so sums, state and scores keep their bits (test_stream_step_kernel_is_bit_identical_to_the_generic_one).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float a) { return f2{a, a}; }
+__device__ __forceinline__ f2 reg_var2(f2 v, float eps) { const f2 t = v + splat2(eps); return f2{fmaxf(t.x, 1e-8f), fmaxf(t.y, 1e-8f)}; }
+__device__ __forceinline__ f2 rcp2(f2 v) { return f2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+__device__ __forceinline__ f2 div_r2(f2 a, f2 b, f2 r) { const f2 q = a * r; return fma2(fma2(-q, b, a), r, q); }
+__device__ __forceinline__ f2 log_normal2(f2 x) {
+    const f2 y = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+    const f2 c = splat2(__uint_as_float(0x3f317217u)), cc = splat2(__uint_as_float(0x3377d1cfu));
+    const f2 r = y * c;
+    return r + fma2(y, cc, fma2(y, c, -r));
+}
+#define UA_LO2(v4) (f2{(v4).x, (v4).y})
+#define UA_HI2(v4) (f2{(v4).z, (v4).w})
+
+// row_logdet_maha on column pairs: accumulators see the same terms in the same order (x, y, z, w of every float4)
+template <int VEC, bool TWO>
+__device__ __forceinline__ void row_logdet_maha_pk(const Row<VEC>& r, const float* xa, const float* xb, float eps, int lane,
+                                                   double& ld, double& ma, double& mb) {
+    const float4* pa = reinterpret_cast<const float4*>(xa);
+    const float4* pb = reinterpret_cast<const float4*>(xb);
+    double al = 0.0, aa = 0.0, ab = 0.0;
+#define UA_LM2(SEL, T)                                                                  \
+        const f2 rv_##T = reg_var2(SEL(r.var[v]), eps);                                 \
+        const f2 rc_##T = rcp2(rv_##T);                                                 \
+        const f2 ln_##T = log_normal2(rv_##T);                                          \
+        const f2 mu_##T = SEL(r.mu[v]);                                                 \
+        const f2 da_##T = SEL(xav) - mu_##T, qa_##T = div_r2(da_##T * da_##T, rv_##T, rc_##T);   \
+        const f2 db_##T = SEL(xbv) - mu_##T, qb_##T = TWO ? div_r2(db_##T * db_##T, rv_##T, rc_##T) : f2{0.f, 0.f};
+#if UA_GMM_SUM4
+#define UA_ACC4P(acc, lo, hi) do { const f2 t_ = (lo) + (hi); acc += (double)(t_.x + t_.y); } while (0)        /* (x + z) + (y + w) */
+#else
+#define UA_ACC4P(acc, lo, hi) do { acc += (double)(lo).x; acc += (double)(lo).y; acc += (double)(hi).x; acc += (double)(hi).y; } while (0)
+#endif
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float4 xav = pa[v * 64 + lane];
+        float4 xbv = xav;
+        if (TWO) xbv = pb[v * 64 + lane];
+        UA_LM2(UA_LO2, l) UA_LM2(UA_HI2, h)
+        UA_ACC4P(al, ln_l, ln_h);
+        UA_ACC4P(aa, qa_l, qa_h);
+        if (TWO) UA_ACC4P(ab, qb_l, qb_h);
+    }
+#undef UA_LM2
+#undef UA_ACC4P
+    ld = wave_sum(al); ma = wave_sum(aa);
+    if (TWO) mb = wave_sum(ab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,6 +376,14 @@ __device__ __forceinline__ float lse_lanes(float v, int M, int lane) {
     return mx + logf(s);
 }
 
+#ifdef UA_GMM_TRACE
+// Instrumented build only (tools/gmm_trace.py): s_memtime stamps of one steady-state class of workgroup 0, per wave.
+__device__ unsigned long long g_gmm_trace[16 * 16];
+#define UA_GSTAMP(i) do { if (blockIdx.x == 0 && lane == 0 && it_ == 3) g_gmm_trace[m * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UA_GSTAMP(i) do { } while (0)
+#endif
+
 // Exchanges per class (one LDS slot each, one barrier between a slot's write and its reads):
 //   A: query joint + first-fit joint of every mode (both use the old pi)   -> barrier A -> scores, responsibilities of fit 1
 //   B: count after fit 1 + second-fit log-likelihood (does not depend on pi) -> barrier B -> every wave forms sum_m c, the
@@ -323,6 +395,7 @@ template <int VEC>
 __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     constexpr int D = 256 * VEC;
     __shared__ __attribute__((aligned(16))) float s_x[3][D];     // query (fp16-rounded if asked), sample, augmented sample
+    __shared__ __attribute__((aligned(16))) float s_xx[2][D];    // squares of the two samples (:213)
     __shared__ float s_jq[kMaxModes], s_j0[kMaxModes], s_c0[kMaxModes], s_l1[kMaxModes], s_c1[kMaxModes];
     const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int M = a.M, K = a.K;
@@ -332,8 +405,9 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         const float q = a.xq[i];
         s_x[0][i] = a.round_q ? round_fp16(q) : q;
-        s_x[1][i] = a.xf[0][i];
-        s_x[2][i] = a.xf[1][i];
+        const float x1 = a.xf[0][i], x2 = a.xf[1][i];
+        s_x[1][i] = x1; s_x[2][i] = x2;
+        s_xx[0][i] = x1 * x1; s_xx[1][i] = x2 * x2;
     }
     Row<VEC> r, nx;
     int k = blockIdx.x;
@@ -349,7 +423,14 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
     __syncthreads();
     const bool now = a.inv_var != nullptr;                                               // final pi needed inside the class body
     bool have_prev = false;                                                              // (wave-uniform)
+#ifdef UA_GMM_TRACE
+    int it_ = -1;
+#endif
     for (; k < K; k += gridDim.x) {
+#ifdef UA_GMM_TRACE
+        ++it_;
+#endif
+        UA_GSTAMP(0);
         const int kn = k + gridDim.x;
         if (kn < K) {
             c_nx = a.c[kn * M + m]; pi_nx = a.pi[kn * M + m]; g0_nx = a.gf[0][kn]; g1_nx = a.gf[1][kn]; cc_nx = a.class_counts[kn];
@@ -357,7 +438,9 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
         }
         const size_t off = ((size_t)k * M + m) * D;
         double ld, mh, mh1 = 0.0;
-        row_logdet_maha<VEC, true>(r, s_x[0], s_x[1], eps, lane, ld, mh, mh1);        // log-det, query and first-fit distances
+        UA_GSTAMP(1);
+        row_logdet_maha_pk<VEC, true>(r, s_x[0], s_x[1], eps, lane, ld, mh, mh1);     // log-det, query and first-fit distances
+        UA_GSTAMP(2);
         {
             const float logpi = logf(pi_km + 1e-10f);
             if (lane == 0) {
@@ -365,7 +448,9 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
                 s_j0[m] = logpi + (float)(-0.5 * (ld + mh1));                           // E-step of fit 1 (:176-180)
             }
         }
+        UA_GSTAMP(3);
         __syncthreads();                                                                // A
+        UA_GSTAMP(4);
         if (have_prev) {                                                                // final pi of the previous class (:229-230)
             float Ck = 0.f;
             for (int i = 0; i < M; ++i) Ck += s_c1[i];
@@ -385,9 +470,12 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             } else {
                 // what this wave contributes to fit 2's E-step: its count and its log-likelihood under the updated row (var changed)
                 double unused;
-                row_logdet_maha<VEC, false>(r, X, X, eps, lane, ld, mh1, unused);
+                UA_GSTAMP(7);
+                row_logdet_maha_pk<VEC, false>(r, X, X, eps, lane, ld, mh1, unused);
                 if (lane == 0) { s_c0[m] = c_km; s_l1[m] = (float)(-0.5 * (ld + mh1)); }
+                UA_GSTAMP(8);
                 __syncthreads();                                                        // B
+                UA_GSTAMP(9);
                 // pi of every mode after fit 1 (:229-230), joint of every mode on the lanes, responsibilities
                 float Ck = 0.f;
                 for (int i = 0; i < M; ++i) Ck += s_c0[i];
@@ -403,25 +491,33 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             const float den = c_new + 1e-10f;
             const float rden = __builtin_amdgcn_rcpf(den);
             const float4* px = reinterpret_cast<const float4*>(X);
-#define UA_UPD1(F)                                                                                    \
+            const float4* pxx = reinterpret_cast<const float4*>(s_xx[f]);
+            if (f == 0) UA_GSTAMP(5); else UA_GSTAMP(10);
+            // two columns per instruction; x*x comes from LDS (formed once per launch: the same product)
+            const f2 g2 = splat2(g), c2 = splat2(c_km), den2 = splat2(den), rden2 = splat2(rden), sg2 = splat2(sum_gamma), m2c = splat2(-2.0f);
+#define UA_UPD2(SEL, LO)                                                                              \
             {                                                                                         \
-                const float mo = r.mu[v].F, vo = r.var[v].F;                                          \
-                const float w1 = g * xv.F, w2 = g * (xv.F * xv.F);  /* :202,:213-214; 0 + g*x of the batched sum dropped (differs for -0 only) */ \
-                const float mn = div_r(c_km * mo + w1, den, rden);                     /* :205-206 */ \
-                const float sq = (w2 + (-2.0f * mo) * w1) + sum_gamma * (mo * mo);     /* :215-217 */ \
-                const float vn = div_r(c_km * vo + sq, den, rden);                     /* :219-220 */ \
-                r.mu[v].F = mn; r.var[v].F = fmaxf(vn, 1e-8f);                         /* :223     */ \
+                const f2 mo = SEL(r.mu[v]), vo = SEL(r.var[v]);                                       \
+                const f2 w1 = g2 * SEL(xv), w2 = g2 * SEL(xxv);     /* :202,:213-214; 0 + g*x of the batched sum dropped (differs for -0 only) */ \
+                const f2 mn = div_r2(c2 * mo + w1, den2, rden2);                       /* :205-206 */ \
+                const f2 sq = (w2 + (m2c * mo) * w1) + sg2 * (mo * mo);                /* :215-217 */ \
+                const f2 vn = div_r2(c2 * vo + sq, den2, rden2);                       /* :219-220 */ \
+                if (LO) { r.mu[v].x = mn.x; r.mu[v].y = mn.y; r.var[v].x = fmaxf(vn.x, 1e-8f); r.var[v].y = fmaxf(vn.y, 1e-8f); }   /* :223 */ \
+                else    { r.mu[v].z = mn.x; r.mu[v].w = mn.y; r.var[v].z = fmaxf(vn.x, 1e-8f); r.var[v].w = fmaxf(vn.y, 1e-8f); }              \
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 const float4 xv = px[v * 64 + lane];
-                UA_UPD1(x) UA_UPD1(y) UA_UPD1(z) UA_UPD1(w)
+                const float4 xxv = pxx[v * 64 + lane];
+                UA_UPD2(UA_LO2, true) UA_UPD2(UA_HI2, false)
             }
-#undef UA_UPD1
+#undef UA_UPD2
             c_km = c_new;
             cc += f ? g1 : g0;                                                          // :233
+            if (f == 0) UA_GSTAMP(6); else UA_GSTAMP(11);
         }
         store_row<VEC>(r, a.mu, a.var, off, lane);
+        UA_GSTAMP(12);
         if (lane == 0) { a.c[k * M + m] = c_km; s_c1[m] = c_km; }
         if (threadIdx.x == 0) a.class_counts[k] = cc;
         if (now) {                                         // workgroup-uniform: pi at once, then gmm_prepare_kernel on the rows still in registers
@@ -445,6 +541,7 @@ __global__ void __launch_bounds__(1024) gmm_step1_kernel(StepArgs a) {
             have_prev = true;
         }
         if (kn < K) { r = nx; c_km = c_nx; pi_km = pi_nx; g0 = g0_nx; g1 = g1_nx; cc = cc_nx; }
+        UA_GSTAMP(13);
     }
     if (have_prev) {                                       // final pi of this workgroup's last class (k has run past it by one stride)
         __syncthreads();
@@ -929,6 +1026,12 @@ static int step_fused_impl(float* mu, float* var, float* pi, float* c, float* cl
         return UA_OK;
     });
 }
+
+#ifdef UA_GMM_TRACE
+extern "C" int ua_debug_gmm_trace(unsigned long long* host256) {
+    return hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_gmm_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ua_gmm_step_fused(float* mu, float* var, float* pi, float* c, float* class_counts,
                                  const float* xq, int32_t xq_round_fp16, const float* x1, const float* x2,

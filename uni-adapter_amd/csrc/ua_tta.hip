@@ -50,7 +50,7 @@ extern "C" int ua_tta_chunk(const ua_tta_state* s, const float* feats, const int
                 ++adam_step;
                 if (adam_step > 0x7fffffff) return UA_EINVAL;
                 // loss + gradient, backward and Adam in one launch (bit-identical to the three entry points)
-                if (K > 128) {
+                if (K > 128 || s->replay_lean) {
                     if ((rc = ua_align_loss(s->L, s->joint, K, M, s->loss, s->grad_ll, stream))) return rc;
                     if ((rc = ua_align_backward(s->mu, s->inv_var, s->e, s->grad_ll, K, K, M, D, s->grad_e, stream))) return rc;
                     if ((rc = ua_residual_adam(s->text0, s->res, s->adam_m, s->adam_v, s->grad_e, s->e, s->norm, K, D,

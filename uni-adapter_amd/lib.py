@@ -45,7 +45,8 @@ class TtaState(C.Structure):
                 ('fhat', _p), ('faug', _p), ('clip_logits', _p), ('prob', _p), ('dota_scores', _p),
                 ('L', _p), ('joint', _p), ('grad_ll', _p), ('grad_e', _p), ('loss', _p),
                 ('inv_var', _p), ('row_const', _p), ('tickets', _p),
-                ('align_mfma', _i32), ('t', _p), ('U', _p), ('align_ws', _p), ('align_ws_bytes', C.c_size_t)]
+                ('align_mfma', _i32), ('t', _p), ('U', _p), ('align_ws', _p), ('align_ws_bytes', C.c_size_t),
+                ('replay_lean', _i32)]
 
 
 # name -> argtypes, exactly the declarations of include/uniadapter.h
@@ -88,6 +89,7 @@ SIGNATURES = {
     'ua_split_f16': [_p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p],
     'ua_gemm_split': [_p, _i64, _f, _p, _i64, _f, _p, _i64, _i32, _i32, _i32, C.POINTER(GemmEpilogue), _p],
     'ua_row_stats_finalize': [_p, _i32, _i64, _i32, _i32, _f, _p, _p],
+    'ua_gemm_split_set_persistent': [_i32],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
     'ua_attention_split': [_p, _i64, _f, _p, _i64, _p, _i64, _f, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
