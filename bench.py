@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--depth', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-similarity', action='store_true')
+    ap.add_argument('--no-comparator', action='store_true', help='skip the vendor-library (hipBLASLt fp16) comparator of the split GEMM')
     ap.add_argument('--cpu-samples', type=int, default=31, help='full-step leg of the CPU baseline: the first N samples of the stream')
     ap.add_argument('--cpu-cache-samples', type=int, default=200, help='cache-only leg of the CPU baseline (median over this many samples)')
     ap.add_argument('--cpu-cache-warmup', type=int, default=20)
@@ -85,7 +86,7 @@ def host_cores():
     return max(1, min(n, cap))
 
 
-PMC_FILES = ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json', 'r02_pmc.json', 'r02b_pmc.json')     # oldest first: later files win
+PMC_FILES = ('r01_pmc_traffic.json', 'r01_f_pmc.json', 'r01_h_pmc.json', 'r02_pmc.json', 'r02b_pmc.json', 'r03_pmc.json')     # oldest first: later files win
 
 
 def _pmc_table():
@@ -513,7 +514,7 @@ def main():
             pa['first_step_max_abs_logit_diff_by_sample'] = [round(float(v), 6) for v in dd]
         out['other_gemm_mode']['prediction_agreement_between_modes'] = pa
     sim_chk = None
-    if rank == 0 and world == 1 and main_mode == 'split':
+    if rank == 0 and world == 1 and main_mode == 'split' and not a.no_comparator:
         try:
             out['roofline']['vendor_library_comparator'] = gemm_comparator(dev)
         except Exception as ex:                                   # a comparator must never take the bench down

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box sweeps for round 3: chunk size, and the lean (three-launch) residual step against the one-launch step (interleaved).
 # usage: bash tools/r03_sweep.sh > gpurun_out/r03_sweep.txt
-B="python bench.py --no-cpu-baseline --no-similarity --no-both-modes --steps 8 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-similarity --no-comparator --no-both-modes --steps 8 --warmup 2"
 val() { python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['executed_frac'])"; }
 for rep in 1 2; do
   for lean in 0 1; do

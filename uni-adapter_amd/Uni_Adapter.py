@@ -202,14 +202,13 @@ class TtaEngine:
         else:
             self.L = self.joint = self.gll = self.ge = self.inv_var = self.row_const = None
             self.loss = e(1)
-        # Residual step in three launches (loss | backward | Adam) instead of the one-launch ua_align_step - bit-identical, ~45 % of
-        # the CU-time, two more launches per Adam step: right where the replay shares the GPU with this rank's own encoder work
-        # (its CU-time comes out of the encoder's), wrong for a dedicated replay rank that the encoder ranks wait on.
+        # Residual step in three launches (loss | backward | Adam) instead of the one-launch ua_align_step: bit-identical, ~45 % less
+        # CU-time (the K x K loss statistics are computed once, not by each of the 4 K workgroups), two more dependent launches per
+        # Adam step.  Beside this rank's own encoder work the replay is paid in CU-time, so this is +1.5 % at chunk 31 - and -1.5 %
+        # at chunk 124, where the longer chain under contention becomes the critical path: off by default.
         env_lean = os.environ.get('UA_REPLAY_LEAN')
-        if replay_lean is None and env_lean is not None:
-            replay_lean = env_lean != '0'
         if replay_lean is None:
-            replay_lean = self.overlap and (self.world == 1 or self.replay_mode in ('replicated', 'streams'))
+            replay_lean = env_lean is not None and env_lean != '0'
         self.replay_lean = bool(replay_lean)
         self.tickets = torch.zeros(K, dtype=torch.int32, device=self.dev)      # hand-off counters of ua_align_step
         self.correct = torch.zeros(3, device=dev, dtype=torch.int64)                          # top-1/3/5 hits

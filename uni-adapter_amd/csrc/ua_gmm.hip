@@ -605,10 +605,12 @@ gmm_prepare_kernel(const float* __restrict__ var, const float* __restrict__ pi, 
     if (lane == 0) row_const[k * M + m] = (float)((double)logf(pi[k * M + m] + 1e-10f) - 0.5 * acc);
 }
 
-constexpr int kAlignQ = 4;      // queries per workgroup in align_fwd_kernel
+// queries per workgroup in align_fwd_kernel (template parameter Q): the workgroup's rows stay in registers for Q queries, so the launch
+// has ceil(B/Q) * K workgroups - fewer, longer workgroups cost the same latency (measured at Q = 2, 4, 8 in round 1) and less
+// CU-time, which is what the replay is paid in when it shares the GPU with the encoder.
 
 // grid (K classes, ceil(B/kAlignQ)), block M*64.  joint[b,k,m] = const[k,m] - 1/2 sum_d (e-mu)^2 * iv
-template <int VEC>
+template <int VEC, int kAlignQ>
 __global__ void __launch_bounds__(1024)
 align_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ inv_var, const float* __restrict__ row_const,
                  const float* __restrict__ e, int B, int K, int M, float* __restrict__ L, float* __restrict__ joint) {
@@ -1070,8 +1072,10 @@ extern "C" int ua_align_forward(const float* mu, const float* inv_var, const flo
     if (int er = check_envelope(K, M, D)) return er;
     return dispatch_vec(D, [&](auto vec) {
         constexpr int VEC = decltype(vec)::value;
-        hipLaunchKernelGGL(align_fwd_kernel<VEC>, dim3(K, (B + kAlignQ - 1) / kAlignQ), dim3(M * 64), 0,
-                           ua::as_stream(stream), mu, inv_var, row_const, e, B, K, M, L, joint);
+        static const int q = [] { const char* e = getenv("UA_ALIGN_FWD_Q"); return e ? atoi(e) : 4; }();
+        if (q >= 20)      hipLaunchKernelGGL((align_fwd_kernel<VEC, 20>), dim3(K, (B + 19) / 20), dim3(M * 64), 0, ua::as_stream(stream), mu, inv_var, row_const, e, B, K, M, L, joint);
+        else if (q >= 10) hipLaunchKernelGGL((align_fwd_kernel<VEC, 10>), dim3(K, (B + 9) / 10), dim3(M * 64), 0, ua::as_stream(stream), mu, inv_var, row_const, e, B, K, M, L, joint);
+        else              hipLaunchKernelGGL((align_fwd_kernel<VEC, 4>), dim3(K, (B + 3) / 4), dim3(M * 64), 0, ua::as_stream(stream), mu, inv_var, row_const, e, B, K, M, L, joint);
         UA_LAUNCH_CHECK();
         return UA_OK;
     });
