@@ -393,7 +393,8 @@ def main():
 
         if world > 1 and eng.replay_mode == 'owner':
             # rho (replay cost / encoder cost per sample) measured here instead of a constant calibrated elsewhere; rank 0's value everywhere
-            rho = eng.calibrate_replay_cost(xyz[:8], rgb[:8], noise[:8])
+            nc = min(n_local, 64)      # at about the batch size an encoder rank really runs (16 clouds measure a 25 % costlier encoder, i.e. a rho too low)
+            rho = eng.calibrate_replay_cost(xyz[:nc], rgb[:nc], noise[:nc])
             log(f'[{precision}] owner mode: measured replay/encoder cost ratio {rho:.3f}')
         log(f'[{precision}] model + stream resident; warm-up')
         first = None

@@ -783,7 +783,7 @@ def test_zeroshot_3d_core(test_loader, validate_dataset_name, model, clip_model,
         pc, rgb, t = torch.cat(buf_pc), torch.cat(buf_rgb), torch.cat(buf_t)
         noise = torch.cat([noise_fn(seen + j, pc[j:j + 1]) for j in range(pc.shape[0])]) if noise_fn else None
         if seen == 0 and eng.world > 1 and eng.replay_mode == 'owner':      # measure the replay / encoder cost ratio on the first clouds
-            m = min(8, pc.shape[0])
+            m = min(64, pc.shape[0])           # the whole first chunk up to 64 samples: the encoder's per-sample cost depends on its batch
             rho = eng.calibrate_replay_cost(pc[:m], rgb[:m], noise[:m] if noise is not None else torch.randn(m, pc.shape[1], 3))
             logging.info(f"owner replay mode: measured replay/encoder cost ratio {rho:.3f}")
         eng.process_chunk(pc, rgb, t, noise)
