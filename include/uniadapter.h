@@ -327,6 +327,11 @@ int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
 int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
                        void* out_split, int64_t ldos, float out_scale,
                        int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
+/* The same for the CLS query of every (cloud, head) only - rows Bc*G .. Bc*G+Bc-1 of the output; q is read for those rows, k and v
+ * for all rows.  For a last transformer block whose patch-token outputs nobody reads (models/point_encoder.py:219 keeps x[:, 0]). */
+int ua_attention_split_cls(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+                       void* out_split, int64_t ldos, float out_scale,
+                       int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
 
 /* Token assembly (models/point_encoder.py:198-208): x[b*G+g] = tok[b*G+g] + pos[b*G+g];
  * x[Bc*G+b] = cls_token + cls_pos.                                                             */

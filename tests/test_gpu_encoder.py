@@ -141,6 +141,40 @@ def test_folded_layernorm_falls_back_to_the_kernels_when_its_first_forward_check
     assert torch.equal(m.encode_pc(pc), want)                        # and stays on the kernels
 
 
+@pytest.mark.parametrize('family,fold', [('uni3d', True), ('uni3d', False), ('openshape', True)])
+def test_last_block_for_the_cls_rows_only_keeps_the_bits(family, fold):
+    """The reference reads only the CLS token after the last block (models/point_encoder.py:219 `norm(x[:, 0])`; OpenShape
+    projects the CLS token), so that block's q / attention / proj / MLP for the patch tokens are dead values.  The encoder then runs
+    them for the CLS rows only (k and v still for all rows): the features must equal the full block's bit for bit, with and without
+    the folded LayerNorms, and `return_tokens=True` must still return every token of the full block."""
+    from uni_adapter_amd import synthetic
+    from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict, create_openshape_from_state_dict
+    pc = _clouds(3, 1024, 23).cuda()
+    if family == 'uni3d':
+        sd = O.make_uni3d_state_dict(9, trans_dim=256, embed_dim=128, enc_dim=512, depth=3)
+        m = create_uni3d_from_state_dict(sd, num_group=256, group_size=64, num_heads=4, precision='split', fold_layernorm=fold)
+        run = lambda: m.encode_pc(pc)
+        run_tok = lambda: m.point_encoder(pc[:, :, :3].contiguous(), pc[:, :, 3:].contiguous(), return_tokens=True)
+    else:
+        m = create_openshape_from_state_dict(synthetic.openshape_state_dict(2, depth=2, out_dim=256, device='cuda'), patches=128, device='cuda',
+                                             precision='split', fold_layernorm=fold)
+        run = lambda: m(pc[:, :, :3].contiguous(), pc.contiguous())
+        run_tok = None
+    enc = m.point_encoder if hasattr(m, 'point_encoder') else m.ppat
+    assert enc.last_block_cls_only
+    lean = run().clone()
+    enc.last_block_cls_only = False
+    full = run().clone()
+    assert torch.equal(lean, full)
+    if run_tok is not None:
+        enc.last_block_cls_only = True
+        out_t, tokens = run_tok()                                   # tokens requested: the block runs in full whatever the switch says
+        assert torch.equal(out_t, full) and torch.isfinite(tokens).all()
+        enc.last_block_cls_only = False
+        _, tokens_full = run_tok()
+        assert torch.equal(tokens, tokens_full)
+
+
 def test_split_schedule_ab_switch_disables_the_fold(monkeypatch):
     """UA_SPLIT_SCHEDULE=8|2 (A/B main loops without the fold prologue) must not leave the folded GEMM calls in place."""
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict

@@ -33,7 +33,7 @@ typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 __global__ void __launch_bounds__(256, 2)
 attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, float c2, float v_inv_scale,
                        float* __restrict__ out, long long ldo, unsigned char* __restrict__ out_split, long long ldos,
-                       float out_scale, int Bc, int G, int H) {
+                       float out_scale, int Bc, int G, int H, int cls_only) {
     __shared__ __attribute__((aligned(16))) unsigned char s_k[2][KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char s_v[2][KT * VROW];
     const int C = H * HD;
@@ -45,7 +45,8 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
     int qb, pair;
     {
         const int nq = n_qb_patch + 1, L = blockIdx.x;
-        if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
+        if (cls_only) { pair = L; qb = n_qb_patch; }                       // one workgroup per (cloud, head): its CLS query only
+        else if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
         else { pair = L / nq; qb = L % nq; }
     }
     const int h = pair % H, b = pair / H;
@@ -326,7 +327,7 @@ attention_split_kernel(const unsigned char* __restrict__ qkv, long long ldqkv, f
 
 }  // namespace
 
-extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+static int attention_split_impl(int cls_only, const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
                                   void* out_split, int64_t ldos, float out_scale,
                                   int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
     UA_CHECK_PTR(qkv); UA_CHECK_ALIGN16(qkv);
@@ -337,11 +338,23 @@ extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scal
     if (out && (ldo % 4 || ldo < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out) & 15))) return UA_EALIGN;
     if (out_split && (ldos % 32 || ldos < (int64_t)H * HD || (reinterpret_cast<uintptr_t>(out_split) & 15) || !(out_scale > 0.f))) return UA_EALIGN;
     if ((long long)(G / 128 + 1) * H * Bc > 0x7fffffffLL) return UA_EUNSUPPORTED;
-    dim3 grid((unsigned)(G / 128 + 1) * H * Bc);
+    dim3 grid(cls_only ? (unsigned)(H * Bc) : (unsigned)(G / 128 + 1) * H * Bc);
     const float c_scale = (0.125f / (qkv_scale * qkv_scale)) * 1.44269504088896340736f;   // hd^-0.5 / s^2 * log2(e)
     hipLaunchKernelGGL(attention_split_kernel, grid, dim3(256), 0, ua::as_stream(stream),
                        reinterpret_cast<const unsigned char*>(qkv), (long long)ldqkv, c_scale, 1.0f / qkv_scale,
-                       out, (long long)ldo, reinterpret_cast<unsigned char*>(out_split), (long long)ldos, out_scale, Bc, G, H);
+                       out, (long long)ldo, reinterpret_cast<unsigned char*>(out_split), (long long)ldos, out_scale, Bc, G, H, cls_only);
     UA_LAUNCH_CHECK();
     return UA_OK;
+}
+
+extern "C" int ua_attention_split(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+                                  void* out_split, int64_t ldos, float out_scale,
+                                  int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+    return attention_split_impl(0, qkv, ldqkv, qkv_scale, out, ldo, out_split, ldos, out_scale, Bc, G, H, hd, stream);
+}
+
+extern "C" int ua_attention_split_cls(const void* qkv, int64_t ldqkv, float qkv_scale, float* out, int64_t ldo,
+                                      void* out_split, int64_t ldos, float out_scale,
+                                      int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+    return attention_split_impl(1, qkv, ldqkv, qkv_scale, out, ldo, out_split, ldos, out_scale, Bc, G, H, hd, stream);
 }
