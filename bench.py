@@ -118,7 +118,8 @@ def pmc_probe(kernel):
 def gemm_comparator(dev):
     """The split GEMM next to the vendor library doing the SAME number of matrix-core products: ua_gemm_split (M,K)x(K,N) executes
     3 f16 MFMAs per product, so torch.matmul in fp16 (hipBLASLt) on (M,3K)x(3K,N) issues as many.  A comparator for the
-    kernel's main loop + epilogue (the library's epilogue is a plain fp16 store), never part of the product path."""
+    kernel's main loop + epilogue (the library's epilogue is a plain fp16 store), never part of the product path.  Five interleaved
+    rounds of 10 launches per side, medians."""
     import ctypes as C
     from uni_adapter_amd import lib
     from uni_adapter_amd.lib import GemmEpilogue
@@ -134,18 +135,18 @@ def gemm_comparator(dev):
         Ah = torch.randn(M, 3 * K, device=dev, dtype=torch.float16); Wh = torch.randn(N, 3 * K, device=dev, dtype=torch.float16)
         theirs = lambda: torch.matmul(Ah, Wh.t())
 
-        def t_us(fn):
-            best = 1e30
-            for _ in range(3):
+        def once(fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
                 fn()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _ in range(10):
-                    fn()
-                b.record(); torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b) * 100.0)
-            return best
-        to, tt = t_us(ours), t_us(theirs)
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) * 100.0
+        ours(); theirs()
+        tso, tst = [], []
+        for _ in range(5):                           # interleaved rounds: both sides see the same clock / thermal state
+            tso.append(once(ours)); tst.append(once(theirs))
+        to, tt = sorted(tso)[2], sorted(tst)[2]      # medians
         fl = 6.0 * M * N * K
         out[name] = {'M': M, 'N': N, 'K': K, 'ua_gemm_split_us': round(to, 1), 'executed_TFLOPs': round(fl / to / 1e6, 1),
                      'hipblaslt_fp16_same_mfma_count_us': round(tt, 1), 'hipblaslt_TFLOPs': round(fl / tt / 1e6, 1), 'ratio': round(to / tt, 3)}

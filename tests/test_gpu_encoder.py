@@ -20,7 +20,7 @@ def _clouds(B, N, seed):
 
 
 @pytest.mark.parametrize('precision', ['f32', 'split'])
-@pytest.mark.parametrize('B,trans_dim,depth,G,embed', [(2, 128, 2, 128, 64), (3, 256, 1, 256, 128)])
+@pytest.mark.parametrize('B,trans_dim,depth,G,embed', [(2, 128, 2, 128, 64), (3, 256, 1, 256, 128), (1, 128, 2, 128, 64)])
 def test_encode_pc_small(B, trans_dim, depth, G, embed, precision):
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
     sd = O.make_uni3d_state_dict(7, trans_dim=trans_dim, embed_dim=embed, enc_dim=512, depth=depth)
