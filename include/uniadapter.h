@@ -318,6 +318,9 @@ int ua_layernorm_split(const float* x, int64_t ldx, const float* w, const float*
  * q|k|v column blocks; out (rows, H*hd).  hd == 64.                                            */
 int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
                  int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
+/* The CLS query of every (cloud, head) only (output rows Bc*G .. Bc*G+Bc-1); see ua_attention_split_cls. */
+int ua_attention_cls(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                     int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream);
 
 /* Same attention with fp32-accurate products on the f16 matrix cores: qkv is an H32L32 split matrix
  * (rows, 3*H*hd) with scale qkv_scale (as emitted by ua_gemm_split's split_out), the result is

@@ -141,7 +141,7 @@ def test_folded_layernorm_falls_back_to_the_kernels_when_its_first_forward_check
     assert torch.equal(m.encode_pc(pc), want)                        # and stays on the kernels
 
 
-@pytest.mark.parametrize('family,fold', [('uni3d', True), ('uni3d', False), ('openshape', True)])
+@pytest.mark.parametrize('family,fold', [('uni3d', True), ('uni3d', False), ('uni3d_f32', False), ('openshape', True)])
 def test_last_block_for_the_cls_rows_only_keeps_the_bits(family, fold):
     """The reference reads only the CLS token after the last block (models/point_encoder.py:219 `norm(x[:, 0])`; OpenShape
     projects the CLS token), so that block's q / attention / proj / MLP for the patch tokens are dead values.  The encoder then runs
@@ -150,9 +150,10 @@ def test_last_block_for_the_cls_rows_only_keeps_the_bits(family, fold):
     from uni_adapter_amd import synthetic
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict, create_openshape_from_state_dict
     pc = _clouds(3, 1024, 23).cuda()
-    if family == 'uni3d':
+    if family.startswith('uni3d'):
         sd = O.make_uni3d_state_dict(9, trans_dim=256, embed_dim=128, enc_dim=512, depth=3)
-        m = create_uni3d_from_state_dict(sd, num_group=256, group_size=64, num_heads=4, precision='split', fold_layernorm=fold)
+        m = create_uni3d_from_state_dict(sd, num_group=256, group_size=64, num_heads=4, precision='f32' if family.endswith('f32') else 'split',
+                                         fold_layernorm=fold)
         run = lambda: m.encode_pc(pc)
         run_tok = lambda: m.point_encoder(pc[:, :, :3].contiguous(), pc[:, :, 3:].contiguous(), return_tokens=True)
     else:

@@ -29,7 +29,7 @@ constexpr int V_LD = HD;               // V tile rows are read 32 consecutive fl
 
 __global__ void __launch_bounds__(256, 2)
 attention_kernel(const float* __restrict__ qkv, long long ldqkv, float* __restrict__ out, long long ldo,
-                 int Bc, int G, int H) {
+                 int Bc, int G, int H, int cls_only) {
     __shared__ __attribute__((aligned(16))) float s_k[2][KT * K_LD];
     __shared__ __attribute__((aligned(16))) float s_v[2][KT * V_LD];
     const int C = H * HD;
@@ -39,7 +39,8 @@ attention_kernel(const float* __restrict__ qkv, long long ldqkv, float* __restri
     int qb, pair;
     {
         const int nq = n_qb_patch + 1, L = blockIdx.x;
-        if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
+        if (cls_only) { pair = L; qb = n_qb_patch; }                       // one workgroup per (cloud, head): its CLS query only
+        else if (((H * Bc) & 7) == 0) { const int slot = L >> 3; pair = (slot / nq) * 8 + (L & 7); qb = slot % nq; }
         else { pair = L / nq; qb = L % nq; }
     }
     const int h = pair % H, b = pair / H;
@@ -169,8 +170,8 @@ attention_kernel(const float* __restrict__ qkv, long long ldqkv, float* __restri
 
 }  // namespace
 
-extern "C" int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
-                            int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+static int attention_impl(int cls_only, const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                          int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
     UA_CHECK_PTR(qkv); UA_CHECK_PTR(out);
     UA_CHECK_ALIGN16(qkv); UA_CHECK_ALIGN16(out);
     if (Bc <= 0 || G <= 0 || H <= 0) return UA_EINVAL;
@@ -178,9 +179,19 @@ extern "C" int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t
     if (ldqkv % 4 || ldo % 4) return UA_EALIGN;
     if (ldqkv < 3LL * H * HD || ldo < (int64_t)H * HD) return UA_EINVAL;
     if ((long long)(G / 128 + 1) * H * Bc > 0x7fffffffLL) return UA_EUNSUPPORTED;
-    dim3 grid((unsigned)(G / 128 + 1) * H * Bc);
+    dim3 grid(cls_only ? (unsigned)(H * Bc) : (unsigned)(G / 128 + 1) * H * Bc);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, ua::as_stream(stream),
-                       qkv, (long long)ldqkv, out, (long long)ldo, Bc, G, H);
+                       qkv, (long long)ldqkv, out, (long long)ldo, Bc, G, H, cls_only);
     UA_LAUNCH_CHECK();
     return UA_OK;
+}
+
+extern "C" int ua_attention(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                            int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+    return attention_impl(0, qkv, ldqkv, out, ldo, Bc, G, H, hd, stream);
+}
+
+extern "C" int ua_attention_cls(const float* qkv, int64_t ldqkv, float* out, int64_t ldo,
+                                int32_t Bc, int32_t G, int32_t H, int32_t hd, void* stream) {
+    return attention_impl(1, qkv, ldqkv, out, ldo, Bc, G, H, hd, stream);
 }

@@ -91,6 +91,7 @@ SIGNATURES = {
     'ua_row_stats_finalize': [_p, _i32, _i64, _i32, _i32, _f, _p, _p],
     'ua_gemm_split_set_persistent': [_i32],
     'ua_attention': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
+    'ua_attention_cls': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p],
     'ua_attention_split': [_p, _i64, _f, _p, _i64, _p, _i64, _f, _i32, _i32, _i32, _i32, _p],
     'ua_attention_split_cls': [_p, _i64, _f, _p, _i64, _p, _i64, _f, _i32, _i32, _i32, _i32, _p],
     'ua_assemble_tokens': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p],

@@ -427,7 +427,7 @@ class PointcloudEncoder(nn.Module):
         the CLS token).  The last block's outputs for the G patch tokens of a cloud are then dead values - the reference computes and
         drops them - so that block projects K and V for all rows (the CLS query attends to every token) but q, the attention, proj and
         the MLP only for the Bc CLS rows: 11.8 of the 338 GFLOP of a Uni3D-L forward are not executed, the CLS features keep their bits
-        (a GEMM output element does not depend on where its tile lies).  Split modes only; UA_LAST_BLOCK_CLS_ONLY=0 runs the block in full."""
+        (a GEMM output element does not depend on where its tile lies).  Both GEMM modes; UA_LAST_BLOCK_CLS_ONLY=0 runs the block in full."""
         G, S, Cd, Hh = self.num_group, self.group_size, self.trans_dim, self.num_heads
         sp = self.precision == 'split'
         st = lib.stream_ptr()
@@ -446,7 +446,7 @@ class PointcloudEncoder(nn.Module):
             first = False
             fold = self.fold_ln
             # r0 / nr: first row and number of rows this block produces (everything after the K / V projection works on row views)
-            cls_only = bool(cls_only_last) and sp and bi == nb - 1 and self.variant != 'ulip' and self.last_block_cls_only
+            cls_only = bool(cls_only_last) and bi == nb - 1 and self.variant != 'ulip' and self.last_block_cls_only
             r0 = Mg if cls_only else 0
             nr = rows - r0
             R = (lambda t: t[r0:]) if cls_only else (lambda t: t)            # row view of a (rows, ...) workspace array
@@ -470,11 +470,13 @@ class PointcloudEncoder(nn.Module):
                 s1 = b.ln1_scale if sp else None
                 _ln(x, Cd, b.n1w, b.n1b, self.ln_eps, w['h'], Cd, rows, Cd, Cd, split_scale=s1)     # (all rows: K and V need them)
             if not sp:
-                _gemm(w['h'], Cd, b.wqkv, w['qkv'], 3 * Cd, rows, 3 * Cd, Cd, bias=b.bqkv)
-                lib.call('ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
+                # (cls_only: k and v - output columns Cd..3Cd - for all rows, q - columns 0..Cd - for the CLS rows)
+                for (ra, nrow, c0, c1) in (((0, rows, Cd, 3 * Cd), (Mg, Bc, 0, Cd)) if cls_only else ((0, rows, 0, 3 * Cd),)):
+                    _gemm(w['h'][ra:], Cd, b.wqkv[c0:c1], w['qkv'][ra:, c0:], 3 * Cd, nrow, c1 - c0, Cd, bias=b.bqkv[c0:c1])
+                lib.call('ua_attention_cls' if cls_only else 'ua_attention', w['qkv'].data_ptr(), 3 * Cd, w['att'].data_ptr(), Cd, Bc, G, Hh, Cd // Hh, st)
                 att, s_att = w['att'], None
                 if b.an_w is not None:
-                    _ln(att, Cd, b.an_w, b.an_b, self.ln_eps, w['h'], Cd, rows, Cd, Cd)
+                    _ln(R(att), Cd, b.an_w, b.an_b, self.ln_eps, R(w['h']), Cd, nr, Cd, Cd)
                     att = w['h']
             else:
                 # q/k/v only ever exist as a split matrix; attention writes its result in split form too
