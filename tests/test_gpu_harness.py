@@ -353,6 +353,39 @@ def test_owner_replay_mode_two_ranks_on_one_gpu(tmp_path):
     assert got['acc'] == ref_acc and torch.load(out + '.r1', weights_only=True)['acc'] == ref_acc
 
 
+def test_full_length_stream_conserves_the_count_mass_and_stays_finite():
+    """A whole ModelNet40-C-sized stream (2 468 samples, `main_test-time.py:68`; K = 40, M = 8, D = 1024, residual learning on) through
+    the composite replay: size-independent properties of the cache step - every sample adds sum_k gamma = 1 twice, so
+    sum(c) = K + 2 n and sum(class_counts) = 2 n (dota_mixture.py:196,233); pi stays a distribution per class; variances stay
+    >= 1e-8; residuals, Adam moments and logits stay finite; the Adam step counter is 10 (n - 1)."""
+    from uni_adapter_amd.Uni_Adapter import TtaEngine
+    g = torch.Generator().manual_seed(5)
+    K, D, M, n, chunk = 40, 1024, 8, 2468, 617
+    text = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    lab = torch.randint(0, K, (n,), generator=g)
+    f0 = torch.nn.functional.normalize(text[lab] + 0.05 * torch.randn(n, D, generator=g), dim=1)
+    f1 = torch.nn.functional.normalize(f0 + 0.02 * torch.randn(n, D, generator=g), dim=1)
+    feats = torch.stack([f0, f1], 1).cuda().contiguous()
+    e = TtaEngine(None, text, {'epsilon': 1e-4, 'sigma': 1e-4, 'eta': 0.1, 'rho': 0.02}, M, res_learning=True, chunk=chunk)
+    dummy = torch.zeros(chunk, 8, 3)
+    hits = 0
+    for c0 in range(0, n, chunk):
+        e.encode_chunk = lambda *a, _f=feats[c0:c0 + chunk]: _f
+        fin, ranks, pred = e.process_chunk(dummy, dummy, lab[c0:c0 + chunk].cuda().int(), dummy)
+        assert torch.isfinite(fin).all() and int(pred.min()) >= 0 and int(pred.max()) < K
+        hits += int((pred.cpu().long() == lab[c0:c0 + chunk]).sum())
+    e.synchronize()
+    m, r = e.mode_dota_model, e.residuals
+    assert abs(float(m.c.double().sum()) - (K + 2 * n)) < 1e-3 * (K + 2 * n)
+    assert abs(float(m.class_counts.double().sum()) - 2 * n) < 1e-3 * 2 * n
+    assert (m.pi.double().sum(1) - 1).abs().max().item() < 1e-5 and float(m.pi.min()) >= 0.0
+    assert float(m.var.min()) >= 1e-8 and torch.isfinite(m.mu).all() and torch.isfinite(m.var).all()
+    for t in (r.res, r.m, r.v, r.e, r.norm):
+        assert torch.isfinite(t).all()
+    assert r.step == 10 * (n - 1) and e.i == n and m.t == 2 * n
+    assert e.accuracy()['acc1'] == pytest.approx(100.0 * hits / n, abs=1e-3) and hits > 0.9 * n      # an easy synthetic stream
+
+
 def test_lean_replay_is_bit_identical_to_the_one_launch_residual_step():
     """ua_tta_state.replay_lean: the residual step as ua_align_loss + ua_align_backward + ua_residual_adam (less CU-time, for a
     replay that shares the GPU with the encoder) against the one-launch ua_align_step (less latency): same final logits,
