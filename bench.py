@@ -155,6 +155,19 @@ def gemm_comparator(dev):
     return out
 
 
+def bench_pmc(kernel, chunk):
+    """HBM traffic per launch of `kernel` over a whole run of THIS bench command under rocprofv3 --pmc (committed table
+    profiles/r03_bench_pmc.json, written by tools/r03_bench_pmc.sh), or None if the table is absent or was taken at another chunk size."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench_pmc.json')))
+        if chunk is None or d.get('chunk') != chunk or kernel not in d['kernels'] or 'traffic_bytes' not in d['kernels'][kernel]:
+            return None
+        k = d['kernels'][kernel]
+        return {'traffic_bytes': k['traffic_bytes'], 'source': f"profiles/r03_bench_pmc.json ({d.get('command', '')}; {k.get('launches_per_pass', '?')} launches per pass)"}
+    except Exception:
+        return None
+
+
 def similarity_roofline(dev):
     """HBM roofline of the similarity kernel and of the fused cache step at configs[4] size (state 2 x 268 MB > Infinity
     Cache), and the batched-query MFMA form.  BEFORE anything is timed, two fused steps, one query and one 8-query MFMA batch
@@ -422,11 +435,11 @@ def main():
         kinds = {k: prof.summary(k) for k in ('f32', 'split')}
         if world > 1:
             # GEMM statistics of ALL ranks (in 'owner' replay mode rank 0 may encode little or nothing)
-            t = torch.tensor([[kinds[k]['flops'], kinds[k]['ms'], kinds[k]['launches']] for k in ('f32', 'split')],
+            t = torch.tensor([[kinds[k]['flops'], kinds[k]['ms'], kinds[k]['launches'], kinds[k]['bytes']] for k in ('f32', 'split')],
                              device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
             for i, k in enumerate(('f32', 'split')):
-                kinds[k] = dict(flops=float(t[i, 0]), ms=float(t[i, 1]), launches=int(t[i, 2]))
+                kinds[k] = dict(flops=float(t[i, 0]), ms=float(t[i, 1]), launches=int(t[i, 2]), bytes=float(t[i, 3]))
         dom = max(kinds, key=lambda k: kinds[k]['ms'])
         g = kinds[dom]
         tfl = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
@@ -441,8 +454,15 @@ def main():
             roof = {'bound': 'mfma', 'achieved': round(tfl, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(tfl / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': 'gemm_f32_mfma_kernel',
                     'mfma_dtype': 'f32'}
-        # `traffic` stays null: the launches of a step have 7 different shapes; the PMC passes were taken on the
-        # qkv shape (16416 x 3072 x 1024) alone and are attached as `pmc_probe`
+        # `traffic`: HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same bench command (tools/r03_bench_pmc.sh:
+        # FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), averaged over all
+        # launches of the kernel like `achieved`; null when no such table is committed for this chunk size.  The counters cannot be read
+        # inside this process, so the field names its source; `pmc_probe` are the passes on the single probe shape.
+        bp = bench_pmc('gemm_split_kernel<16, 3>' if dom == 'split' else 'gemm_f32_mfma_kernel', n_local if world == 1 else None)
+        if bp is not None:
+            roof['traffic'] = bp['traffic_bytes']
+            roof['traffic_source'] = bp['source']
+        roof['algorithmic_bytes_per_launch_avg'] = g['bytes'] / max(1, g['launches'])
         roof['pmc_probe'] = (pmc_probe('gemm_split_kernel<16, 3>') or pmc_probe('gemm_split_kernel<16>')) if dom == 'split' else pmc_probe('gemm_f32_mfma_kernel')
         roof.update({'launches': g['launches'], 'flops_per_launch_avg': g['flops'] / max(1, g['launches']),
                      'ms_per_launch_avg': round(g['ms'] / max(1, g['launches']), 5),

@@ -36,7 +36,7 @@ class GemmProfiler:
         recs = [r for r in self.records if kind is None or r[3] == kind]
         flops = sum(r[2] for r in recs)
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-        return dict(launches=len(recs), flops=flops, ms=ms)
+        return dict(launches=len(recs), flops=flops, ms=ms, bytes=sum(r[4] for r in recs))
 
 
 PROFILER = None          # set to a GemmProfiler to time every GEMM launch
@@ -129,7 +129,12 @@ def _gemm(A, lda, W, out, ldc, M, N, K, bias=None, scale=None, shift=None, rowgr
         kind = 'f32'
     if prof is not None:
         ev1.record()
-        prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K, kind))
+        # algorithmic bytes of the launch: both operands once, every output array once, the residual once (4 bytes per element in
+        # either storage form; a SwiGLU launch writes N / 2 columns)
+        n_out = N // 2 if act == ACT_SWIGLU else N
+        outs = (out is not None) + (split_out is not None) + (residual is not None)
+        alg_bytes = 4.0 * (M * K + N * K + outs * M * n_out) + (4.0 * (M // max(1, pool_rows)) * n_out if pool_out is not None else 0.0)
+        prof.records.append((ev0, ev1, alg_flops if alg_flops is not None else 2.0 * M * N * K, kind, alg_bytes))
 
 
 def _row_stats(stats, n_parts, rows, n, eps, out):
