@@ -496,6 +496,10 @@ def main():
                                + ('on' if cfg['res'] else 'off') + ') on synthetic 1024-pt clouds; BASELINE.json configs[1]',
                    'samples_per_rank_per_step': n_local, 'global_samples_per_step': n_global, 'encoder_depth': a.depth,
                    'gemm_mode': main_mode,
+                   'last_block': ('q / attention / proj / MLP for the CLS rows only - the reference keeps x[:, 0] alone after the blocks '
+                                  '(models/point_encoder.py:219), so the patch-token outputs of the last block are dead values; features '
+                                  'bit-identical (tests), 11.8 of 338 GFLOP per forward not executed; UA_LAST_BLOCK_CLS_ONLY=0 runs it in full (-2.8 %)'
+                                  if os.environ.get('UA_LAST_BLOCK_CLS_ONLY', '1') != '0' else 'in full (UA_LAST_BLOCK_CLS_ONLY=0)'),
                    'replay_overlap': bool(a.overlap),
                    'parallelism': (f'sample-sharded encoder x{world}, in-order cache replay on rank 0 (its encoder share reduced to balance), '
                                    f'1 all_gather/step' if world > 1 and os.environ.get('UA_REPLAY_MODE', 'owner') == 'owner' else
