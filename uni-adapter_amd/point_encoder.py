@@ -174,7 +174,7 @@ class PointcloudEncoder(nn.Module):
         self.dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.num_group, self.group_size, self.num_heads = int(num_group), int(group_size), int(num_heads)
         self.ln_eps, self.fps_start, self.fps_skip_eps = float(ln_eps), int(fps_start), float(fps_skip_eps)
-        self.pe_clouds = int(pe_clouds)
+        self.pe_clouds = int(os.environ.get('UA_PE_CLOUDS', pe_clouds))      # clouds per mini-PointNet slice (its per-point activations are 64 MB per cloud)
         if precision not in ('f32', 'split'):
             raise ValueError("precision must be 'f32' (exact-f32 MFMA) or 'split' (3xf16-split MFMA, fp32-accurate)")
         self.precision = precision
