@@ -142,13 +142,14 @@ def test_folded_layernorm_falls_back_to_the_kernels_when_its_first_forward_check
 
 
 @pytest.mark.parametrize('family,fold', [('uni3d', True), ('uni3d', False), ('uni3d_f32', False), ('openshape', True)])
-def test_last_block_for_the_cls_rows_only_keeps_the_bits(family, fold):
+def test_last_block_for_the_cls_rows_only_keeps_the_bits(family, fold, monkeypatch):
     """The reference reads only the CLS token after the last block (models/point_encoder.py:219 `norm(x[:, 0])`; OpenShape
     projects the CLS token), so that block's q / attention / proj / MLP for the patch tokens are dead values.  The encoder then runs
     them for the CLS rows only (k and v still for all rows): the features must equal the full block's bit for bit, with and without
     the folded LayerNorms, and `return_tokens=True` must still return every token of the full block."""
     from uni_adapter_amd import synthetic
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict, create_openshape_from_state_dict
+    monkeypatch.delenv('UA_LAST_BLOCK_CLS_ONLY', raising=False)
     pc = _clouds(3, 1024, 23).cuda()
     if family.startswith('uni3d'):
         sd = O.make_uni3d_state_dict(9, trans_dim=256, embed_dim=128, enc_dim=512, depth=3)
@@ -180,6 +181,7 @@ def test_split_schedule_ab_switch_disables_the_fold(monkeypatch):
     """UA_SPLIT_SCHEDULE=8|2 (A/B main loops without the fold prologue) must not leave the folded GEMM calls in place."""
     from uni_adapter_amd.point_encoder import create_uni3d_from_state_dict
     sd = O.make_uni3d_state_dict(5, trans_dim=128, embed_dim=64, enc_dim=512, depth=1)
+    monkeypatch.delenv('UA_FOLD_LN', raising=False)                  # (the suite is also run under UA_FOLD_LN=0)
     monkeypatch.setenv('UA_SPLIT_SCHEDULE', '8')
     m = create_uni3d_from_state_dict(sd, num_group=128, group_size=64, num_heads=2, precision='split')
     assert not m.point_encoder.fold_ln
